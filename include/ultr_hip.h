@@ -1,0 +1,229 @@
+/*
+ * ultr_hip.h -- C ABI of libultr_hip.so: the MI355X (gfx950) hot path of ULTRA's offline
+ * unbiased-LTR training step, as hand-written HIP kernels.
+ *
+ * The reference (ULTR-Community/ULTRA) has no C/FFI boundary: its hot path is a TensorFlow-1
+ * graph driven through Python plugin classes.  Each entry point below therefore cites the
+ * reference Python/TF op sequence it replaces (file:line relative to the reference checkout);
+ * the Python classes in ultra_amd/ mirror the reference's plugin API and bind these symbols
+ * with ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _h (host);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return 0 on success, negative ULTR_E* on error; ultr_last_error() gives the text;
+ *   - no entry point allocates or frees device memory, synchronises, or keeps state between
+ *     calls other than what the caller passes in (workspaces), so calls are capturable in a
+ *     hipGraph and re-entrant per stream (two calls sharing one workspace must be ordered);
+ *   - "position-major" [L][B]: element (list b, rank l) is at l*B + b, i.e. the row order of
+ *     DNN.build's axis-0 concat (DNN.py:65);
+ *   - a doc id equal to n_rows denotes the zero pad row (base_algorithm.py:120-123).
+ */
+#ifndef ULTR_HIP_H_
+#define ULTR_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULTR_VERSION 100 /* 0.1.0 */
+
+#define ULTR_OK 0
+#define ULTR_EINVAL (-1)  /* bad argument (shape, enum, null pointer)           */
+#define ULTR_ELIMIT (-2)  /* size beyond a compiled-in limit                    */
+#define ULTR_EHIP (-3)    /* a HIP runtime call failed (launch error)           */
+
+#define ULTR_MAX_LAYERS 8
+#define ULTR_MAX_LIST 64     /* max rank_list_size for the loss / feed kernels   */
+#define ULTR_MAX_SORT 2048   /* max list length for the metric sort              */
+#define ULTR_MAX_WIDTH 1024  /* max hidden width                                 */
+
+/* activation_func (base_ranking_model.py:59-65) */
+enum { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1, ULTR_ACT_SELU = 2, ULTR_ACT_TANH = 3, ULTR_ACT_SIGMOID = 4 };
+/* norm hparam (DNN.py:32,70): "layer" or anything else = no normalisation */
+enum { ULTR_NORM_NONE = 0, ULTR_NORM_LAYER = 1 };
+/* click models on the device path (click_models.py:74-116, 194-241) */
+enum { ULTR_CLICK_PBM = 0, ULTR_CLICK_CASCADE = 1, ULTR_CLICK_ORACLE = 2 /* oracle_mode: labels as clicks */ };
+/* loss_func hparam (dla.py:129-134, ipw_rank.py:135-143) */
+enum { ULTR_LOSS_SOFTMAX = 0, ULTR_LOSS_SIGMOID = 1 };
+/* logits_to_prob hparam (dla.py:99-101) */
+enum { ULTR_PROB_SOFTMAX = 0, ULTR_PROB_SIGMOID = 1 };
+/* grad_strategy hparam (dla.py:183-185) */
+enum { ULTR_OPT_ADAGRAD = 0, ULTR_OPT_SGD = 1 };
+/* metric bits for ultr_metrics */
+enum { ULTR_METRIC_MRR = 1, ULTR_METRIC_NDCG = 2, ULTR_METRIC_ERR = 4 };
+
+/* Shape of the DNN scorer (DNN.py:25-34, :67-94) and where each variable lives in the flat
+ * fp32 parameter buffer.  Layer j: LayerNorm(gamma_j, beta_j over its INPUT width) ->
+ * W_j [in_j, sizes[j]] row-major -> + b_j -> activation (hidden layers only). */
+typedef struct UltrDnnDesc {
+  int n_layers;                 /* hidden layers + the output layer                  */
+  int in_features;              /* F                                                 */
+  int sizes[ULTR_MAX_LAYERS];   /* output width per layer; sizes[n_layers-1] must be 1 */
+  int activation;               /* ULTR_ACT_*                                        */
+  int norm;                     /* ULTR_NORM_*                                       */
+  float ln_eps;                 /* keras LayerNormalization epsilon (1e-3)           */
+  long long off_W[ULTR_MAX_LAYERS];     /* offsets in floats, each a multiple of 4   */
+  long long off_b[ULTR_MAX_LAYERS];
+  long long off_gamma[ULTR_MAX_LAYERS];
+  long long off_beta[ULTR_MAX_LAYERS];
+  long long n_params;           /* length of the flat buffer (padding included)      */
+} UltrDnnDesc;
+
+int ultr_version(void);
+const char* ultr_last_error(void);
+
+/* ---- data set preparation -------------------------------------------------------------
+ * Per-row LayerNorm statistics of the feature table: stats[r] = (mean, 1/sqrt(var+eps)) over
+ * the F features of row r, for r < n_rows; stats[n_rows] = those of the zero pad row.
+ * Layer 0 of DNN.build normalises the raw feature rows (DNN.py:78-81), and those statistics
+ * depend only on the data, so they are computed once per table instead of every step.
+ * x: [n_rows][ldx] fp32, ldx >= F, ldx % 4 == 0.  stats: [(n_rows+1)][2]. */
+int ultr_ln_row_stats(const float* x, long long n_rows, int F, int ldx, float eps, float* stats,
+                      void* stream);
+
+/* ---- click simulation (click_models.py:86-116 PBM, :204-241 cascade) --------------------
+ * labels [n][L] fp32 relevance grades -> clicks [n][L] fp32 in {0,1}.
+ * click = [u < exam[min(rank,n_exam-1)] * click_prob[clamp(int(label))]] in float64.
+ * uniforms != NULL: [n][L] float64 draws (bit-exact reproduction of a supplied stream);
+ * uniforms == NULL: Philox4x32-10, counter (list, 0, block, stream_step), key = seed.
+ * exam / click_prob are device float64 tables. */
+int ultr_click_pbm(const float* labels, long long n, int L, const double* exam, int n_exam,
+                   const double* click_prob, int n_click_prob, const double* uniforms,
+                   unsigned long long seed, unsigned int stream_step, float* clicks, void* stream);
+int ultr_click_cascade(const float* labels, long long n, int L, const double* exam, int n_exam,
+                       const double* click_prob, int n_click_prob, const double* uniforms,
+                       unsigned long long seed, unsigned int stream_step, float* clicks, void* stream);
+
+/* ---- batch assembly: ClickSimulationFeed.get_batch (click_simulation_feed.py:107-162) ---
+ * Rejection-samples B query lists with >= 1 click (when check_validation) from a data set
+ * resident on the device and emits the feed tensors position-major.
+ *   initial_list [Q][Lmax] int32 (doc row ids, -1 = pad), labels [Q][Lmax] fp32.
+ *   out_docids [L][B] int32 (pad -> n_rows), out_clicks [L][B] fp32, out_list_idx [B] int32.
+ * mode 0 (Philox, parallel): slot s = slot_base + b draws attempt t = 0.. on its own stream
+ *   (counter (s, t, block, step)); draw 0 picks the list (int(u*Q), :132), draws 1..L are the
+ *   clicks (:87).  After max_attempts rejected attempts the last candidate is kept.
+ * mode 1 (sequential, bit-exact with a supplied random.random() stream): uniforms
+ *   [n_cand][1+L] float64; candidates are consumed in order, accepted ones fill slots
+ *   slot_start.. ; info[0] = candidates consumed, info[1] = slots filled so far.
+ * step_ctr (mode 0, may be NULL): device uint32 added to `step` and incremented once per call by
+ *   the last workgroup to finish -- kernel arguments are frozen in a hipGraph, this is not.
+ * info: int32[4] device, zero-initialised: {consumed, filled, total_attempts, arrival counter}. */
+int ultr_batch_assemble(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
+                        int click_model, const double* exam, int n_exam, const double* click_prob,
+                        int n_click_prob, int mode, unsigned long long seed, unsigned int step,
+                        unsigned int* step_ctr,
+                        unsigned int slot_base, const double* uniforms, int n_cand, int slot_start,
+                        int check_validation, int max_attempts, int n_rows, int* out_docids,
+                        float* out_clicks, int* out_list_idx, int* info, void* stream);
+
+/* ---- DNN scorer (DNN.py:48-96 via base_algorithm.py:104-134) ---------------------------- */
+/* Bytes of workspace ultr_dnn_forward/backward need for M rows (M = L*B). */
+long long ultr_dnn_workspace_bytes(const UltrDnnDesc* desc, long long M);
+
+/* scores[m] = DNN(table[docids[m]]) for m < M.  table [n_rows][ldx]; table_stats from
+ * ultr_ln_row_stats (may be NULL when desc->norm == ULTR_NORM_NONE).  Keeps activations and
+ * LayerNorm statistics in `workspace` for ultr_dnn_backward. */
+int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, const float* table,
+                     const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                     void* workspace, float* scores, void* stream);
+
+/* grads[0..n_params) = d(sum_m d_scores[m] * scores[m]) / d params  (replaces tf.gradients,
+ * dla.py:237-239 etc.).  Must follow ultr_dnn_forward with the same arguments/workspace. */
+int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, const float* table,
+                      const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                      void* workspace, const float* d_scores, float* grads, void* stream);
+
+/* ---- losses, forward + backward in one pass -------------------------------------------
+ * All take scores/clicks position-major [L][B] and write d_scores [L][B] UN-NORMALISED: the
+ * caller's optimiser call divides by the batch-global normaliser in `stats` (this is what
+ * makes data-parallel runs exact: sums are all-reduced, then divided once).
+ * `ws` is a float workspace of ultr_loss_workspace_floats(B, L) floats, zero-initialised once
+ * (the kernels leave its arrival counter at zero). */
+long long ultr_loss_workspace_floats(int B, int L);
+
+/* softmax_loss with per-element weights (base_algorithm.py:228-251), IPWrank's default loss
+ * (ipw_rank.py:141-143); pw [L][B].  loss_func SIGMOID = sigmoid_loss_on_list (:163-186).
+ * stats[0] = sum_b loss_b (numerator), stats[1] = normaliser (sum wl, or B for sigmoid),
+ * stats[2+l] = max_b pw[l][b]  ("Propensity weights %d" summary, ipw_rank.py:120-125).
+ * list_weights [B] = mean_l(pw*clip(c,0,1))  (ipw_rank.py:180-181), may be NULL. */
+int ultr_loss_ipw_fwdbwd(const float* scores, const float* clicks, const float* pw, int B, int L,
+                         int loss_func, float* d_scores, float* stats, float* list_weights, float* ws,
+                         void* stream);
+
+/* IPW weights from a propensity table (propensity_estimator.py:33-42): pw = ipw[min(l,n-1)]
+ * where clicks > 0 else 0.  ipw: device fp32 [n_ipw]. */
+int ultr_ipw_weights(const float* clicks, int B, int L, const float* ipw, int n_ipw, float* pw,
+                     void* stream);
+
+/* DLA (dla.py:119-180, DenoisingNet :257-306, get_normalized_weights :343-364).
+ * prop_params: [L+1] = W_0[0..L) then b_0.  Outputs:
+ *   d_scores [L][B]   un-normalised d rank_loss / d train_output (divide by stats[1])
+ *   prop_grads [L+1]  un-normalised d exam_loss / d (W_0, b_0)    (divide by stats[3])
+ *   list_weights [B]  mean_l(pw_l * clip(c,0,1))                  (dla.py:207-208)
+ *   stats: [0] rank numerator [1] rank normaliser [2] exam numerator [3] exam normaliser
+ *          [4+l] pw_l   [4+L+l] sum_b rw[b][l]   (summaries dla.py:147-172) */
+int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* prop_params,
+                         int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
+                         float* prop_grads, float* list_weights, float* stats, float* ws, void* stream);
+
+/* Regression-EM (regression_EM.py:116-176).  propensity [L] is the EM state (read, pre-update
+ * value used for loss and gradient, q16).  uniforms [L][B] fp32 or NULL (Philox(seed, step)).
+ *   d_scores un-normalised (divide by B_global); d_bias[0] (may be NULL) = sum of d_scores, the
+ *   un-normalised gradient of sigmoid_prob_b;
+ *   stats: [0] sum_b loss_b  [1] B  [2+l] sum_b (c + (1-c) P(e=1,r=0|c=0))  (M-step numerator)
+ *          [2+L+l] sum_b ranker_label  [2+2L+l] sum_b clicks   ("Additional pseudo clicks")
+ *          [2+3L] sum of d_scores = un-normalised gradient of sigmoid_prob_b
+ *   Philox draws are keyed by (slot_base + b, l), so a data-parallel shard reproduces its
+ *   slice of the one-big-batch run.
+ *   list_weights [B] = mean_l(clip(c,0,1)/propensity_l)  (regression_EM.py:176,216-217). */
+int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* propensity,
+                         const float* sigmoid_prob_b, const float* uniforms, unsigned long long seed,
+                         unsigned int step, const unsigned int* step_ctr, unsigned int slot_base,
+                         float* d_scores, float* ranker_labels,
+                         float* list_weights,
+                         float* stats, float* d_bias, float* ws, void* stream);
+
+/* EM state update from all-reduced statistics: p <- (1-s) p + s * stats[2+l]/stats[1]. */
+int ultr_rem_update_propensity(float* propensity, int L, const float* stats, float em_step_size,
+                               float* old_out /* [L] pre-update values, may be NULL */, void* stream);
+
+/* Pairwise debiasing (pairwise_debias.py:139-171, pair CE base_algorithm.py:151-161).
+ * t_plus/t_minus [L] state (pre-update values used).  d_scores is already final (the loss is a
+ * batch SUM).  stats: [0..L*L) pair-loss matrix l_ij (sum_b), to be all-reduced before
+ * ultr_pd_update_ratios; stats[L*L] = loss. */
+int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* t_plus,
+                        const float* t_minus, float* d_scores, float* stats, float* ws, void* stream);
+int ultr_pd_update_ratios(float* t_plus, float* t_minus, int L, float* stats, float em_step_size,
+                          float regulation_p, float* old_out /* [2L] pre-update t+,t-; may be NULL */,
+                          void* stream);
+
+/* ---- metrics (metrics.py:215-323,445-481; sort metric_utils.py:49-86) --------------------
+ * scores/labels [Lx][B] position-major.  docids (may be NULL) [Lx][B]: entries == n_rows get
+ * PADDING_SCORE first (base_algorithm.py:64-87).  list_weights [B] or NULL (per-list weights).
+ * u_pred [B][Lx] fp32 tie-break uniforms or NULL (ties then fall back to lower index first).
+ * out[(m*n_topn + t)*2 + w]: m in order MRR, NDCG, ERR (those selected in metric_mask),
+ * w = 0 plain / 1 weighted (only written when list_weights != NULL).  topn_h: host ints.
+ * ws: ultr_metrics_workspace_floats(B) floats, zero-initialised once. */
+long long ultr_metrics_workspace_floats(int B, int n_topn);
+int ultr_metrics(const float* scores, const float* labels, const int* docids, int n_rows,
+                 const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
+                 int n_topn, int metric_mask, float max_label, float* out, float* ws, void* stream);
+/* The permutation itself: perm [B][topn] int32 = sort_by_scores(scores) indices. */
+int ultr_sort_by_scores(const float* scores, const float* u, int B, int Lx, int topn, int* perm,
+                        void* stream);
+
+/* ---- optimiser (tf.clip_by_global_norm + Adagrad/SGD, dla.py:240-255 etc.) ---------------
+ * g = grads * scale_const / (*denom or 1) + l2 * theta;  norm = ||g||_2;
+ * if clip_norm > 0: g *= clip_norm / max(norm, clip_norm);
+ * Adagrad: acc += g^2; theta -= lr * g / sqrt(acc)  (acc starts at 0.1, no epsilon); SGD:
+ * theta -= lr*g.  out_norm (device float, may be NULL) receives the pre-clip norm.
+ * ws: at least 1024+8 floats, zero-initialised once. */
+int ultr_clip_adagrad(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                      float scale_const, float l2, float clip_norm, float lr, int strategy,
+                      float* out_norm, float* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTR_HIP_H_ */

@@ -1,0 +1,113 @@
+"""ctypes binding of libultr_hip.so (the C ABI declared in include/ultr_hip.h).
+
+The library is the product: there is no CPU fallback.  ``lib()`` raises if the shared object
+is missing, and every wrapper raises ``UltrError`` with the library's own message when an
+entry point returns a negative code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libultr_hip.so')
+
+ULTR_MAX_LAYERS = 8
+ULTR_MAX_LIST = 64
+
+ACT = {'elu': 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid': 4}
+NORM_NONE, NORM_LAYER = 0, 1
+CLICK_PBM, CLICK_CASCADE, CLICK_ORACLE = 0, 1, 2
+LOSS_SOFTMAX, LOSS_SIGMOID = 0, 1
+PROB_SOFTMAX, PROB_SIGMOID = 0, 1
+OPT_ADAGRAD, OPT_SGD = 0, 1
+METRIC_BITS = {'mrr': 1, 'ndcg': 2, 'err': 4}
+METRIC_ORDER = ('mrr', 'ndcg', 'err')
+
+
+class UltrError(RuntimeError):
+    pass
+
+
+class UltrDnnDesc(ctypes.Structure):
+    _fields_ = [
+        ('n_layers', ctypes.c_int),
+        ('in_features', ctypes.c_int),
+        ('sizes', ctypes.c_int * ULTR_MAX_LAYERS),
+        ('activation', ctypes.c_int),
+        ('norm', ctypes.c_int),
+        ('ln_eps', ctypes.c_float),
+        ('off_W', ctypes.c_longlong * ULTR_MAX_LAYERS),
+        ('off_b', ctypes.c_longlong * ULTR_MAX_LAYERS),
+        ('off_gamma', ctypes.c_longlong * ULTR_MAX_LAYERS),
+        ('off_beta', ctypes.c_longlong * ULTR_MAX_LAYERS),
+        ('n_params', ctypes.c_longlong),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_U = ctypes.c_uint
+_LL = ctypes.c_longlong
+_ULL = ctypes.c_ulonglong
+_F = ctypes.c_float
+_DESC = ctypes.POINTER(UltrDnnDesc)
+
+# name -> (restype, argtypes); mirrors include/ultr_hip.h one to one
+SIGNATURES = {
+    'ultr_version': (_I, []),
+    'ultr_last_error': (ctypes.c_char_p, []),
+    'ultr_ln_row_stats': (_I, [_P, _LL, _I, _I, _F, _P, _P]),
+    'ultr_click_pbm': (_I, [_P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),
+    'ultr_click_cascade': (_I, [_P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),
+    'ultr_batch_assemble': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _ULL, _U, _P, _U, _P, _I, _I,
+                                 _I, _I, _I, _P, _P, _P, _P, _P]),
+    'ultr_dnn_workspace_bytes': (_LL, [_DESC, _LL]),
+    'ultr_dnn_forward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P]),
+    'ultr_dnn_backward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P, _P]),
+    'ultr_loss_workspace_floats': (_LL, [_I, _I]),
+    'ultr_loss_ipw_fwdbwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'ultr_ipw_weights': (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    'ultr_loss_dla_fwdbwd': (_I, [_P, _P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    'ultr_loss_rem_fwdbwd': (_I, [_P, _P, _I, _I, _P, _P, _P, _ULL, _U, _P, _U, _P, _P, _P, _P, _P, _P, _P]),
+    'ultr_rem_update_propensity': (_I, [_P, _I, _P, _F, _P, _P]),
+    'ultr_loss_pd_fwdbwd': (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    'ultr_pd_update_ratios': (_I, [_P, _P, _I, _P, _F, _F, _P, _P]),
+    'ultr_metrics_workspace_floats': (_LL, [_I, _I]),
+    'ultr_metrics': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
+    'ultr_sort_by_scores': (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    'ultr_clip_adagrad': (_I, [_P, _P, _P, _LL, _P, _F, _F, _F, _F, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libultr_hip.so (once).  Fails loudly: the HIP library IS the implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UltrError(
+                'libultr_hip.so not found at %s -- build it with `make -C ultra_amd/csrc` '
+                '(or __graft_entry__.build()); ultra_amd has no CPU fallback' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc < 0:
+        raise UltrError('%s failed (%d): %s' % (what, rc, lib().ultr_last_error().decode()))
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,142 @@
+// Shared device helpers for libultr_hip (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ultr_hip.h"
+
+namespace ultr {
+
+// ---- error plumbing (host) ---------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define ULTR_REQUIRE(cond, code, ...)          \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::ultr::set_error(__VA_ARGS__);          \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+// ---- wave / block reductions (wave = 64 lanes) -------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 32 lanes of one wave half (xor offsets < 32 never cross the halves)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum of NV values per thread; result valid in every thread.  `red` is LDS scratch of
+// at least NV * (blockDim.x/64) floats.  Deterministic (fixed order).
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[i * nw + wid] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[i * nw + w];
+    v[i] = s;
+  }
+}
+
+// ---- cross-workgroup "last arriver reduces" hand-off (agent-scope release/acquire) --------
+// Every block stores its partials with plain stores, then calls arrive(); the call returns true
+// in exactly one block (the last to arrive), after which that block may read every block's
+// partials with plain loads.  The counter is left at zero for the next launch.
+__device__ __forceinline__ bool last_block_arrive(unsigned int* counter, unsigned int n_blocks) {
+  __shared__ unsigned int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int last = (t == n_blocks - 1) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0u;
+}
+
+// ---- Philox4x32-10 -------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t v[4];
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+// two 32-bit words -> double in [0,1), the genrand_res53 construction of CPython's random.random()
+__host__ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+// 32-bit word -> float in [0,1) (24 bits)
+__host__ __device__ __forceinline__ float u24(uint32_t a) { return (float)(a >> 8) * (1.0f / 16777216.0f); }
+
+// ---- activations (base_ranking_model.py:59-65), derivative through the OUTPUT value ---------
+#define ULTR_SELU_ALPHA 1.6732632423543772848170429916717f
+#define ULTR_SELU_SCALE 1.0507009873554804934193349852946f
+
+__device__ __forceinline__ float act_fwd(int kind, float z) {
+  switch (kind) {
+    case ULTR_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case ULTR_ACT_RELU: return fmaxf(z, 0.f);
+    case ULTR_ACT_SELU: return ULTR_SELU_SCALE * (z >= 0.f ? z : ULTR_SELU_ALPHA * expm1f(z));
+    case ULTR_ACT_TANH: return tanhf(z);
+    default: return 1.f / (1.f + expf(-z));
+  }
+}
+__device__ __forceinline__ float act_grad_from_out(int kind, float a) {
+  switch (kind) {
+    case ULTR_ACT_ELU: return a > 0.f ? 1.f : a + 1.f;
+    case ULTR_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+    case ULTR_ACT_SELU: return a > 0.f ? ULTR_SELU_SCALE : a + ULTR_SELU_SCALE * ULTR_SELU_ALPHA;
+    case ULTR_ACT_TANH: return 1.f - a * a;
+    default: return a * (1.f - a);
+  }
+}
+
+}  // namespace ultr

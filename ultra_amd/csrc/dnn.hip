@@ -1,0 +1,897 @@
+// DNN list scorer: forward and backward as LDS-tiled fp32-MFMA GEMMs with fused
+// LayerNorm / bias / activation, for gfx950 (MI355X).
+//
+// Reference: ultra/ranking_model/DNN.py:63-96 (LN(input) -> matmul -> bias_add -> activation per
+// layer; rows are the position-major concat of the list, :65), feature gather + zero pad row
+// ultra/learning_algorithm/base_algorithm.py:120-132, gradients = tf.gradients (dla.py:237-239).
+//
+// Design notes:
+//  * exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain, so the parity bound is the
+//    fp32 one (1e-5); one wave owns one 32x32 accumulator tile (16 VGPRs).
+//  * LayerNorm of layer j's input needs full-row statistics, but a GEMM tile only sees 32 columns
+//    of a row.  The producing layer's epilogue writes per-(row, 32-column group) partial (sum,
+//    M2); the consuming kernel merges them with Chan's formula (two-pass quality, fixed order,
+//    no atomics).  Layer 0 normalises raw feature rows, whose statistics depend on the data
+//    only: they are precomputed once per table (ultr_ln_row_stats).
+//  * the feature gather (K1) is fused into the layer-0 A-tile load, forward and backward.
+//  * backward per layer: wgrad G = xhat^T dz (split over rows into slabs, reduced in fixed order
+//    by the finalize kernel; dW = gamma*G + beta x S, dgamma = sum_n W*G, dbeta = sum_n W*S, so
+//    layer 0 needs no dgrad GEMM at all), dgrad dh = dz W^T, then a row pass applies the
+//    LayerNorm backward and the activation derivative (from the stored activation output).
+#include "common.hpp"
+
+namespace ultr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 16;        // contraction chunk per LDS stage
+constexpr int LDK = BK + 4;   // row stride of a k-contiguous LDS tile (conflict-free ds_read_b128)
+constexpr int kThreads = 256; // 4 waves
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout (all offsets in floats)
+// ---------------------------------------------------------------------------------------------
+struct Layout {
+  int H;                               // hidden layers
+  int K[ULTR_MAX_LAYERS];              // input width of layer j
+  int N[ULTR_MAX_LAYERS];              // output width of layer j
+  int ldn[ULTR_MAX_LAYERS];            // padded output width (multiple of 4) = row stride of W_j, act_j, dz
+  long long act[ULTR_MAX_LAYERS];      // [M][ldn_j]        activations of hidden layer j
+  long long part[ULTR_MAX_LAYERS];     // [M][ntile_j][2]   partial LN stats of act_j
+  long long stat[ULTR_MAX_LAYERS + 1]; // [M][2]            (mean, rstd) of layer j's input, j >= 1
+  long long dz[2];                     // [M][maxld]        ping-pong gradient buffers
+  int nsplit[ULTR_MAX_LAYERS];
+  int rows_per_split[ULTR_MAX_LAYERS];
+  long long gslab[ULTR_MAX_LAYERS];    // [nsplit][K_j][ldn_j]
+  long long sslab[ULTR_MAX_LAYERS];    // [nsplit][ldn_j]
+  int out_rows_per_block, out_blocks;
+  long long outpart;                   // [out_blocks][3*Kout + 4]
+  int maxld;
+  long long total;
+};
+
+static inline int round4(int x) { return (x + 3) & ~3; }
+
+static Layout make_layout(const UltrDnnDesc* d, long long M) {
+  Layout L;
+  L.H = d->n_layers - 1;
+  long long off = 0;
+  auto take = [&](long long n) {
+    long long o = off;
+    off += (n + 63) & ~63ll;
+    return o;
+  };
+  int cur = d->in_features;
+  L.maxld = 4;
+  for (int j = 0; j < d->n_layers; ++j) {
+    L.K[j] = cur;
+    L.N[j] = d->sizes[j];
+    L.ldn[j] = round4(d->sizes[j]);
+    cur = d->sizes[j];
+  }
+  for (int j = 0; j < L.H; ++j) {
+    if (L.ldn[j] > L.maxld) L.maxld = L.ldn[j];
+    L.act[j] = take(M * L.ldn[j]);
+    L.part[j] = take(M * ((L.N[j] + 31) / 32) * 2);
+  }
+  for (int j = 0; j <= L.H; ++j) L.stat[j] = take(M * 2);
+  L.dz[0] = take(M * L.maxld);
+  L.dz[1] = take(M * L.maxld);
+  for (int j = 0; j < L.H; ++j) {
+    const long long tiles = cdiv(L.K[j], 64) * cdiv(L.N[j], 64);
+    long long want = cdiv(256, tiles);  // ~one workgroup per CU per layer
+    const long long max_split = cdiv(M, 64);
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    long long rps = cdiv(cdiv(M, want), BK) * BK;
+    L.rows_per_split[j] = (int)rps;
+    L.nsplit[j] = (int)cdiv(M, rps);
+    L.gslab[j] = take((long long)L.nsplit[j] * L.K[j] * L.ldn[j]);
+    L.sslab[j] = take((long long)L.nsplit[j] * L.ldn[j]);
+  }
+  long long rpb = cdiv(M, 512);  // aim for <= 512 partial rows
+  if (rpb < 16) rpb = 16;
+  rpb = cdiv(rpb, 4) * 4;
+  L.out_rows_per_block = (int)rpb;
+  L.out_blocks = (int)cdiv(M, rpb);
+  L.outpart = take((long long)L.out_blocks * (3 * L.K[L.H] + 4));
+  L.total = off;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-row LayerNorm statistics of a dense table (layer 0 input), one wave per row, two-pass
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) ln_row_stats_kernel(const float* __restrict__ x, long long n_rows, int F,
+                                                                int ldx, float eps, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r > n_rows) return;
+  if (r == n_rows) {  // the zero pad row (base_algorithm.py:120-123): mean 0, var 0
+    if (lane == 0) {
+      stats[2 * r] = 0.f;
+      stats[2 * r + 1] = 1.f / sqrtf(eps);
+    }
+    return;
+  }
+  const float* row = x + r * ldx;
+  float s = 0.f;
+  for (int k = lane; k < F; k += 64) s += row[k];
+  const float mean = wave_sum(s) / (float)F;
+  float m2 = 0.f;
+  for (int k = lane; k < F; k += 64) {
+    const float d = row[k] - mean;
+    m2 += d * d;
+  }
+  const float var = wave_sum(m2) / (float)F;  // biased variance (keras LayerNormalization)
+  if (lane == 0) {
+    stats[2 * r] = mean;
+    stats[2 * r + 1] = 1.f / sqrtf(var + eps);
+  }
+}
+
+// merge the per-32-column partials (sum, M2) of one row into (mean, rstd)   [Chan et al.]
+__device__ __forceinline__ float2 merge_partials(const float* __restrict__ part, int N, float eps) {
+  const int ntile = (N + 31) >> 5;
+  float total = 0.f;
+  for (int g = 0; g < ntile; ++g) total += part[2 * g];
+  const float mean = total / (float)N;
+  float m2 = 0.f;
+  for (int g = 0; g < ntile; ++g) {
+    const int cnt = min(32, N - 32 * g);
+    const float d = part[2 * g] / (float)cnt - mean;
+    m2 += part[2 * g + 1] + (float)cnt * d * d;
+  }
+  return make_float2(mean, 1.f / sqrtf(m2 / (float)N + eps));
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA micro-kernels.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; over the 8 steps of a BK=16 chunk, lane half h walks k = 8h + t.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_frag_kcontig(const float* __restrict__ tile, int row, int h, float (&f)[8]) {
+  const float4 v0 = *reinterpret_cast<const float4*>(tile + row * LDK + 8 * h);
+  const float4 v1 = *reinterpret_cast<const float4*>(tile + row * LDK + 8 * h + 4);
+  f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+  f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+}
+__device__ __forceinline__ void load_frag_kmajor(const float* __restrict__ tile, int ld, int col, int h,
+                                                 float (&f)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) f[t] = tile[(8 * h + t) * ld + col];
+}
+__device__ __forceinline__ void mma8(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+}
+// accumulator register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------
+// forward hidden layer:  act[m][n] = f( LN(x_m) . W[:,n] + b[n] )      tile 32 rows x 128 cols
+// ---------------------------------------------------------------------------------------------
+struct FwdArgs {
+  // input rows: either gathered from the table (layer 0) or dense
+  const float* x;          // table [n_rows][ldx]  or  act_{j-1} [M][ldx]
+  int ldx;
+  const int* docids;       // != NULL: gather rows x[docids[m]] ; docid == n_rows -> zero row
+  int n_rows;
+  const float* row_stats;  // gather: table_stats [(n_rows+1)][2] ; dense: unused
+  const float* part_in;    // dense + LN: partial stats of the input [M][ntile_in][2]
+  float* stat_out;         // dense + LN: merged (mean, rstd) [M][2], written by the first column tile
+  int has_ln;
+  float eps;
+  const float* gamma; const float* beta; const float* W; const float* bias;
+  int K, N, ldn;
+  long long M;
+  int activation;
+  float* act_out;          // [M][ldn]
+  float* part_out;         // [M][ntile_out][2]
+};
+
+__global__ void __launch_bounds__(kThreads) fwd_layer_kernel(FwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[2][32 * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * 128];
+  __shared__ float s_stat[32][2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const long long m0 = (long long)blockIdx.x * 32;
+  const int n0 = blockIdx.y * 128;
+
+  // --- row statistics of this block's 32 input rows
+  if (tid < 32) {
+    const long long m = m0 + tid;
+    float2 st = make_float2(0.f, 1.f);
+    if (m < p.M && p.has_ln) {
+      if (p.docids) {
+        const int d = p.docids[m];
+        st = make_float2(p.row_stats[2 * (long long)d], p.row_stats[2 * (long long)d + 1]);
+      } else {
+        st = merge_partials(p.part_in + m * (((p.K + 31) >> 5) * 2), p.K, p.eps);
+        if (blockIdx.y == 0) {
+          p.stat_out[2 * m] = st.x;
+          p.stat_out[2 * m + 1] = st.y;
+        }
+      }
+    }
+    s_stat[tid][0] = st.x;
+    s_stat[tid][1] = st.y;
+  }
+  __syncthreads();
+
+  // --- staging assignments
+  // A: 32 rows x 16 k = 128 float4 -> threads 0..127: row = tid/4, quad = tid%4
+  const int a_row = tid >> 2, a_q = tid & 3;
+  const bool a_thread = tid < 128;
+  const long long a_m = m0 + a_row;
+  const float* a_src = nullptr;
+  float a_mean = 0.f, a_rstd = 1.f;
+  if (a_thread && a_m < p.M) {
+    if (p.docids) {
+      const int d = p.docids[a_m];
+      a_src = d < p.n_rows ? p.x + (long long)d * p.ldx : nullptr;  // pad row: zeros
+    } else {
+      a_src = p.x + a_m * p.ldx;
+    }
+    a_mean = s_stat[a_row][0];
+    a_rstd = s_stat[a_row][1];
+  }
+  const bool a_live = a_thread && a_m < p.M;
+  // B: 16 k x 128 cols = 512 float4 -> 2 per thread: f = tid + 256*i, row = f/32, c4 = f%32
+  float4 ra, rb0, rb1;
+  auto load_chunk = [&](int k0) {
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ka = k0 + 4 * a_q;
+    if (a_live && ka < p.K) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_src) x = *reinterpret_cast<const float4*>(a_src + ka);
+      if (p.has_ln) {
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + ka);
+        const float4 b = *reinterpret_cast<const float4*>(p.beta + ka);
+        x.x = (x.x - a_mean) * a_rstd * g.x + b.x;
+        x.y = (x.y - a_mean) * a_rstd * g.y + b.y;
+        x.z = (x.z - a_mean) * a_rstd * g.z + b.z;
+        x.w = (x.w - a_mean) * a_rstd * g.w + b.w;
+      }
+      // k beyond K inside this quad -> 0 (the row stride is padded, the values are not ours)
+      if (ka + 1 >= p.K) x.y = 0.f;
+      if (ka + 2 >= p.K) x.z = 0.f;
+      if (ka + 3 >= p.K) x.w = 0.f;
+      ra = x;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f >> 5, c = n0 + 4 * (f & 31);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + row < p.K && c < p.ldn) v = *reinterpret_cast<const float4*>(p.W + (long long)(k0 + row) * p.ldn + c);
+      if (i == 0) rb0 = v; else rb1 = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    if (a_thread) *reinterpret_cast<float4*>(&As[buf][a_row * LDK + 4 * a_q]) = ra;
+    *reinterpret_cast<float4*>(&Bs[buf][(tid >> 5) * 128 + 4 * (tid & 31)]) = rb0;
+    *reinterpret_cast<float4*>(&Bs[buf][((tid + 256) >> 5) * 128 + 4 * (tid & 31)]) = rb1;
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nchunk = (p.K + BK - 1) / BK;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) load_chunk((c + 1) * BK);
+    float a[8], b[8];
+    load_frag_kcontig(As[buf], l31, h, a);
+    load_frag_kmajor(Bs[buf], 128, w * 32 + l31, h, b);
+    mma8(a, b, acc);
+    if (c + 1 < nchunk) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue: bias + activation + store + partial LayerNorm statistics of the output rows
+  const int col = n0 + w * 32 + l31;
+  const int colbase = n0 + w * 32;
+  const int cnt = min(32, p.N - colbase);
+  const bool col_ok = col < p.N;
+  const float bias = col_ok ? p.bias[col] : 0.f;
+  const int ntile_out = (p.N + 31) >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long long m = m0 + acc_row(r, h);
+    float v = col_ok ? act_fwd(p.activation, acc[r] + bias) : 0.f;
+    if (m < p.M && col < p.ldn) p.act_out[m * p.ldn + col] = v;
+    if (cnt > 0) {
+      const float sum = half_sum(v);
+      const float mu = sum / (float)cnt;
+      const float dv = col_ok ? v - mu : 0.f;
+      const float m2 = half_sum(dv * dv);
+      if (l31 == 0 && m < p.M) {
+        float* dst = p.part_out + (m * ntile_out + (colbase >> 5)) * 2;
+        dst[0] = sum;
+        dst[1] = m2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// output layer (width 1):  score[m] = LN(x_m) . w + b          one wave per row
+// ---------------------------------------------------------------------------------------------
+struct OutArgs {
+  const float* x; int ldx; const int* docids; int n_rows; const float* row_stats;
+  const float* part_in; float* stat_out; int has_ln; float eps;
+  const float* gamma; const float* beta; const float* W; const float* bias;
+  int K; long long M; float* scores;
+};
+
+__device__ __forceinline__ float2 out_row_stats(const OutArgs& p, long long m, const float** src) {
+  float2 st = make_float2(0.f, 1.f);
+  if (p.docids) {
+    const int d = p.docids[m];
+    *src = d < p.n_rows ? p.x + (long long)d * p.ldx : nullptr;
+    if (p.has_ln) st = make_float2(p.row_stats[2 * (long long)d], p.row_stats[2 * (long long)d + 1]);
+  } else {
+    *src = p.x + m * p.ldx;
+    if (p.has_ln) st = merge_partials(p.part_in + m * (((p.K + 31) >> 5) * 2), p.K, p.eps);
+  }
+  return st;
+}
+
+__global__ void __launch_bounds__(kThreads) fwd_out_kernel(OutArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  const float* src;
+  const float2 st = out_row_stats(p, m, &src);
+  if (p.has_ln && !p.docids && lane == 0) {
+    p.stat_out[2 * m] = st.x;
+    p.stat_out[2 * m + 1] = st.y;
+  }
+  float s = 0.f;
+  for (int k = lane; k < p.K; k += 64) {
+    const float x = src ? src[k] : 0.f;
+    const float hk = p.has_ln ? (x - st.x) * st.y * p.gamma[k] + p.beta[k] : x;
+    s += hk * p.W[k];
+  }
+  s = wave_sum(s);
+  if (lane == 0) p.scores[m] = s + p.bias[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the output layer: parameter-gradient partials + dz of the last hidden layer
+// ---------------------------------------------------------------------------------------------
+struct BwdOutArgs {
+  OutArgs f;               // same operands as the forward (stat_out is read here)
+  const float* stat_in;    // dense: merged stats written by fwd_out_kernel [M][2]
+  const float* d_scores;   // [M]
+  int activation;          // of the previous hidden layer
+  int has_prev;            // 1: write dz for the previous hidden layer
+  float* dz; int lddz;     // [M][lddz]
+  int rows_per_block;
+  float* partials;         // [gridDim.x][3K+4]: dW[K], dgamma[K], dbeta[K], db
+};
+
+__global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
+  extern __shared__ float smem[];  // [4 waves][3K+1]
+  const int K = p.f.K;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* acc = smem + w * (3 * K + 1);
+  for (int i = lane; i < 3 * K + 1; i += 64) acc[i] = 0.f;
+  const long long m_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long m_end = m_begin + p.rows_per_block;
+  if (m_end > p.f.M) m_end = p.f.M;
+  float db = 0.f;
+  for (long long m = m_begin + w; m < m_end; m += 4) {
+    const float go = p.d_scores[m];
+    const float* src;
+    float2 st = make_float2(0.f, 1.f);
+    if (p.f.docids) {
+      st = out_row_stats(p.f, m, &src);
+    } else {
+      src = p.f.x + m * p.f.ldx;
+      if (p.f.has_ln) st = make_float2(p.stat_in[2 * m], p.stat_in[2 * m + 1]);
+    }
+    db += go;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float x = src ? src[k] : 0.f;
+      const float wk = p.f.W[k];
+      if (p.f.has_ln) {
+        const float xh = (x - st.x) * st.y;
+        const float g = p.f.gamma[k];
+        acc[k] += (g * xh + p.f.beta[k]) * go;  // dW
+        acc[K + k] += go * wk * xh;             // dgamma
+        acc[2 * K + k] += go * wk;              // dbeta
+        s1 += go * wk * g;
+        s2 += go * wk * g * xh;
+      } else {
+        acc[k] += x * go;
+      }
+    }
+    if (p.has_prev) {
+      if (p.f.has_ln) {
+        s1 = wave_sum(s1) / (float)K;
+        s2 = wave_sum(s2) / (float)K;
+      }
+      for (int k = lane; k < p.lddz; k += 64) {
+        float v = 0.f;
+        if (k < K) {
+          const float a = src[k];
+          float dx = go * p.f.W[k];
+          if (p.f.has_ln) {
+            const float xh = (a - st.x) * st.y;
+            dx = st.y * (dx * p.f.gamma[k] - s1 - xh * s2);
+          }
+          v = dx * act_grad_from_out(p.activation, a);
+        }
+        p.dz[m * p.lddz + k] = v;
+      }
+    }
+  }
+  if (lane == 0) acc[3 * K] = db;
+  __syncthreads();
+  float* out = p.partials + (long long)blockIdx.x * (3 * K + 4);
+  for (int i = threadIdx.x; i < 3 * K + 1; i += blockDim.x) {
+    const int stride = 3 * K + 1;
+    out[i] = smem[i] + smem[stride + i] + smem[2 * stride + i] + smem[3 * stride + i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad:  G[k][n] = sum_m xhat[m][k] * dz[m][n]   (+ S[n] = sum_m dz[m][n])
+// tile 64 (k) x 64 (n), 4 waves as 2x2; rows m split over blockIdx.z into slabs
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x; int ldx; const int* docids; int n_rows; const float* row_stats;  // gather (layer 0)
+  const float* stat_in;    // dense: [M][2]
+  int has_ln;
+  const float* dz; int ldn; int N;   // [M][ldn]
+  int K; long long M; int rows_per_split;
+  float* gslab;            // [nsplit][K][ldn]
+  float* sslab;            // [nsplit][ldn]
+};
+
+__global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK * 64];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int wr = w >> 1, wc = w & 1;
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const long long m_begin = (long long)blockIdx.z * p.rows_per_split;
+  long long m_end = m_begin + p.rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int s_row = tid >> 4, s_c = 4 * (tid & 15);  // staging: 16 rows x 16 float4
+  float4 ra, rb;
+  auto load_chunk = [&](long long mc) {
+    const long long m = mc + s_row;
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = ra;
+    if (m < m_end) {
+      const int ka = k0 + s_c;
+      if (ka < p.K) {
+        const float* src;
+        float2 st = make_float2(0.f, 1.f);
+        if (p.docids) {
+          const int d = p.docids[m];
+          src = d < p.n_rows ? p.x + (long long)d * p.ldx : nullptr;
+          if (p.has_ln) st = make_float2(p.row_stats[2 * (long long)d], p.row_stats[2 * (long long)d + 1]);
+        } else {
+          src = p.x + m * p.ldx;
+          if (p.has_ln) st = make_float2(p.stat_in[2 * m], p.stat_in[2 * m + 1]);
+        }
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src) x = *reinterpret_cast<const float4*>(src + ka);
+        if (p.has_ln) {
+          x.x = (x.x - st.x) * st.y; x.y = (x.y - st.x) * st.y;
+          x.z = (x.z - st.x) * st.y; x.w = (x.w - st.x) * st.y;
+        }
+        if (ka + 1 >= p.K) x.y = 0.f;
+        if (ka + 2 >= p.K) x.z = 0.f;
+        if (ka + 3 >= p.K) x.w = 0.f;
+        ra = x;
+      }
+      const int nb = n0 + s_c;
+      if (nb < p.ldn) rb = *reinterpret_cast<const float4*>(p.dz + m * p.ldn + nb);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    *reinterpret_cast<float4*>(&As[buf][s_row * 64 + s_c]) = ra;
+    *reinterpret_cast<float4*>(&Bs[buf][s_row * 64 + s_c]) = rb;
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum = 0.f;
+  const bool do_colsum = blockIdx.x == 0 && tid < 64;
+  const int nchunk = (int)((m_end - m_begin + BK - 1) / BK);
+  if (nchunk > 0) {
+    load_chunk(m_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) load_chunk(m_begin + (long long)(c + 1) * BK);
+    float a[8], b[8];
+    load_frag_kmajor(As[buf], 64, wr * 32 + l31, h, a);
+    load_frag_kmajor(Bs[buf], 64, wc * 32 + l31, h, b);
+    mma8(a, b, acc);
+    if (do_colsum) {
+#pragma unroll
+      for (int r = 0; r < BK; ++r) colsum += Bs[buf][r * 64 + tid];
+    }
+    if (c + 1 < nchunk) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+  float* g = p.gslab + (long long)blockIdx.z * p.K * p.ldn;
+  const int col = n0 + wc * 32 + l31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int k = k0 + wr * 32 + acc_row(r, h);
+    if (k < p.K && col < p.ldn) g[(long long)k * p.ldn + col] = acc[r];
+  }
+  if (do_colsum && n0 + tid < p.ldn) p.sslab[(long long)blockIdx.z * p.ldn + n0 + tid] = colsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dgrad:  dh[m][k] = sum_n dz[m][n] * W[k][n]        tile 32 rows x 128 cols (k)
+// ---------------------------------------------------------------------------------------------
+struct DgradArgs {
+  const float* dz; int ldn; int N;   // [M][ldn] (contraction over n < N)
+  const float* W;                    // [K][ldn]
+  int K; int ldk;                    // output width and its padded stride
+  long long M;
+  float* dh;                         // [M][ldk]
+};
+
+__global__ void __launch_bounds__(kThreads) dgrad_kernel(DgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[2][32 * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][128 * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const long long m0 = (long long)blockIdx.x * 32;
+  const int k0 = blockIdx.y * 128;
+  const int a_row = tid >> 2, a_q = tid & 3;
+  const bool a_thread = tid < 128;
+  float4 ra, rb0, rb1;
+  auto load_chunk = [&](int n0) {
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int na = n0 + 4 * a_q;
+    if (a_thread && m0 + a_row < p.M && na < p.ldn)
+      ra = *reinterpret_cast<const float4*>(p.dz + (m0 + a_row) * p.ldn + na);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;  // 128 rows x 4 quads
+      const int row = f >> 2, q = f & 3;
+      const int nb = n0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + row < p.K && nb < p.ldn) v = *reinterpret_cast<const float4*>(p.W + (long long)(k0 + row) * p.ldn + nb);
+      if (i == 0) rb0 = v; else rb1 = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    if (a_thread) *reinterpret_cast<float4*>(&As[buf][a_row * LDK + 4 * a_q]) = ra;
+    *reinterpret_cast<float4*>(&Bs[buf][(tid >> 2) * LDK + 4 * (tid & 3)]) = rb0;
+    *reinterpret_cast<float4*>(&Bs[buf][((tid + 256) >> 2) * LDK + 4 * (tid & 3)]) = rb1;
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nchunk = (p.N + BK - 1) / BK;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) load_chunk((c + 1) * BK);
+    float a[8], b[8];
+    load_frag_kcontig(As[buf], l31, h, a);
+    load_frag_kcontig(Bs[buf], w * 32 + l31, h, b);
+    mma8(a, b, acc);
+    if (c + 1 < nchunk) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+  const int col = k0 + w * 32 + l31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long long m = m0 + acc_row(r, h);
+    if (m < p.M && col < p.ldk) p.dh[m * p.ldk + col] = acc[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row pass: dz = LayerNorm-backward(dh) * act'(a), in place.  One wave per row.
+//   g = dh*gamma ; dx = rstd * (g - mean(g) - xhat*mean(g*xhat)) ; dz = dx * act'(a)
+// ---------------------------------------------------------------------------------------------
+struct RowpassArgs {
+  float* dh; int ldk; int K; long long M;
+  const float* a;          // activations of the layer whose output this is [M][ldk]
+  const float* stat;       // (mean, rstd) of those rows [M][2] (LN of the NEXT layer's input)
+  const float* gamma;
+  int has_ln; int activation;
+};
+
+__global__ void __launch_bounds__(kThreads) rowpass_kernel(RowpassArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  float* row = p.dh + m * p.ldk;
+  const float* a = p.a + m * p.ldk;
+  float mean = 0.f, rstd = 1.f, c1 = 0.f, c2 = 0.f;
+  if (p.has_ln) {
+    mean = p.stat[2 * m];
+    rstd = p.stat[2 * m + 1];
+    for (int k = lane; k < p.K; k += 64) {
+      const float g = row[k] * p.gamma[k];
+      c1 += g;
+      c2 += g * (a[k] - mean) * rstd;
+    }
+    c1 = wave_sum(c1) / (float)p.K;
+    c2 = wave_sum(c2) / (float)p.K;
+  }
+  for (int k = lane; k < p.K; k += 64) {
+    const float ak = a[k];
+    float dx = row[k];
+    if (p.has_ln) dx = rstd * (dx * p.gamma[k] - c1 - (ak - mean) * rstd * c2);
+    row[k] = dx * act_grad_from_out(p.activation, ak);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: reduce slabs in fixed order and form the parameter gradients
+//   dW[k][n] = gamma_k G[k][n] + beta_k S[n] ; db[n] = S[n]
+//   dgamma_k = sum_n W[k][n] G[k][n] ; dbeta_k = sum_n W[k][n] S[n]
+// one block per (hidden layer, input row k); the last block reduces the output-layer partials
+// ---------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+  int H;
+  int row_start[ULTR_MAX_LAYERS + 1];  // block index ranges per layer
+  int K[ULTR_MAX_LAYERS], N[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS], nsplit[ULTR_MAX_LAYERS];
+  const float* gslab[ULTR_MAX_LAYERS];
+  const float* sslab[ULTR_MAX_LAYERS];
+  long long off_W[ULTR_MAX_LAYERS], off_b[ULTR_MAX_LAYERS], off_gamma[ULTR_MAX_LAYERS], off_beta[ULTR_MAX_LAYERS];
+  const float* params;
+  float* grads;
+  int has_ln;
+  const float* outpart; int out_blocks; int Kout;
+};
+
+__global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
+  __shared__ float red[8];
+  const int blk = blockIdx.x;
+  if (blk == p.row_start[p.H]) {  // output layer
+    const int K = p.Kout, j = p.H;
+    for (int i = threadIdx.x; i < 3 * K + 1; i += blockDim.x) {
+      float s = 0.f;
+      for (int b = 0; b < p.out_blocks; ++b) s += p.outpart[(long long)b * (3 * K + 4) + i];
+      if (i < K) p.grads[p.off_W[j] + i] = s;  // W_out is a plain [K] vector
+      else if (i < 2 * K) { if (p.has_ln) p.grads[p.off_gamma[j] + (i - K)] = s; }
+      else if (i < 3 * K) { if (p.has_ln) p.grads[p.off_beta[j] + (i - 2 * K)] = s; }
+      else p.grads[p.off_b[j]] = s;
+    }
+    return;
+  }
+  int j = 0;
+  while (blk >= p.row_start[j + 1]) ++j;
+  const int k = blk - p.row_start[j];
+  const int ldn = p.ldn[j], N = p.N[j], ns = p.nsplit[j];
+  const float* W = p.params + p.off_W[j] + (long long)k * ldn;
+  float* dW = p.grads + p.off_W[j] + (long long)k * ldn;
+  const float gam = p.has_ln ? p.params[p.off_gamma[j] + k] : 1.f;
+  const float bet = p.has_ln ? p.params[p.off_beta[j] + k] : 0.f;
+  float v[2] = {0.f, 0.f};
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float G = 0.f, S = 0.f;
+    for (int s = 0; s < ns; ++s) {
+      G += p.gslab[j][((long long)s * p.K[j] + k) * ldn + n];
+      S += p.sslab[j][(long long)s * ldn + n];
+    }
+    dW[n] = gam * G + bet * S;
+    const float wv = W[n];
+    v[0] += wv * G;
+    v[1] += wv * S;
+    if (k == 0) p.grads[p.off_b[j] + n] = S;
+  }
+  if (p.has_ln) {
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+      p.grads[p.off_gamma[j] + k] = v[0];
+      p.grads[p.off_beta[j] + k] = v[1];
+    }
+  }
+}
+
+}  // namespace ultr
+
+using namespace ultr;
+
+static int check_desc(const UltrDnnDesc* d, const char* who) {
+  ULTR_REQUIRE(d, ULTR_EINVAL, "%s: null descriptor", who);
+  ULTR_REQUIRE(d->n_layers >= 1 && d->n_layers <= ULTR_MAX_LAYERS, ULTR_ELIMIT, "%s: n_layers=%d not in [1,%d]", who,
+               d->n_layers, ULTR_MAX_LAYERS);
+  ULTR_REQUIRE(d->in_features >= 1, ULTR_EINVAL, "%s: in_features=%d", who, d->in_features);
+  ULTR_REQUIRE(d->sizes[d->n_layers - 1] == 1, ULTR_EINVAL, "%s: output_size must be 1 (scores are [B,1], DNN.py:33)",
+               who);
+  for (int j = 0; j + 1 < d->n_layers; ++j)
+    ULTR_REQUIRE(d->sizes[j] >= 1 && d->sizes[j] <= ULTR_MAX_WIDTH, ULTR_ELIMIT, "%s: hidden width %d not in [1,%d]",
+                 who, d->sizes[j], ULTR_MAX_WIDTH);
+  ULTR_REQUIRE(d->activation >= ULTR_ACT_ELU && d->activation <= ULTR_ACT_SIGMOID, ULTR_EINVAL, "%s: activation=%d",
+               who, d->activation);
+  ULTR_REQUIRE(d->norm == ULTR_NORM_NONE || d->norm == ULTR_NORM_LAYER, ULTR_EINVAL,
+               "%s: norm=%d (batch normalisation is not on the device path)", who, d->norm);
+  for (int j = 0; j < d->n_layers; ++j)
+    ULTR_REQUIRE((d->off_W[j] & 3) == 0 && (d->off_b[j] & 3) == 0 && (d->off_gamma[j] & 3) == 0 &&
+                     (d->off_beta[j] & 3) == 0,
+                 ULTR_EINVAL, "%s: parameter offsets must be multiples of 4 floats", who);
+  return ULTR_OK;
+}
+
+extern "C" long long ultr_dnn_workspace_bytes(const UltrDnnDesc* desc, long long M) {
+  if (check_desc(desc, "ultr_dnn_workspace_bytes") != ULTR_OK || M <= 0) return -1;
+  return make_layout(desc, M).total * (long long)sizeof(float);
+}
+
+extern "C" int ultr_ln_row_stats(const float* x, long long n_rows, int F, int ldx, float eps, float* stats,
+                                 void* stream) {
+  ULTR_REQUIRE(x && stats, ULTR_EINVAL, "ultr_ln_row_stats: null pointer");
+  ULTR_REQUIRE(n_rows >= 0 && F > 0 && ldx >= F, ULTR_EINVAL, "ultr_ln_row_stats: bad sizes n_rows=%lld F=%d ldx=%d",
+               n_rows, F, ldx);
+  hipLaunchKernelGGL(ln_row_stats_kernel, dim3((unsigned)cdiv(n_rows + 1, 4)), dim3(kThreads), 0, as_stream(stream), x,
+                     n_rows, F, ldx, eps, stats);
+  return check_launch("ln_row_stats_kernel");
+}
+
+static int common_checks(const char* who, const UltrDnnDesc* desc, const float* params, const float* table,
+                         const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                         void* workspace) {
+  int rc = check_desc(desc, who);
+  if (rc) return rc;
+  ULTR_REQUIRE(params && table && docids && workspace, ULTR_EINVAL, "%s: null pointer", who);
+  ULTR_REQUIRE(desc->norm == ULTR_NORM_NONE || table_stats, ULTR_EINVAL, "%s: table_stats required with norm=layer",
+               who);
+  ULTR_REQUIRE(M > 0 && n_rows >= 0, ULTR_EINVAL, "%s: bad sizes M=%lld n_rows=%d", who, M, n_rows);
+  ULTR_REQUIRE(ldx >= desc->in_features && (ldx & 3) == 0, ULTR_EINVAL,
+               "%s: table row stride %d must be >= F=%d and a multiple of 4", who, ldx, desc->in_features);
+  ULTR_REQUIRE(((uintptr_t)params & 15) == 0 && ((uintptr_t)table & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
+               ULTR_EINVAL, "%s: params/table must be 16-byte and workspace 256-byte aligned", who);
+  ULTR_REQUIRE(M / 32 + 1 < 2147483647ll, ULTR_ELIMIT, "%s: M=%lld too large", who, M);
+  return ULTR_OK;
+}
+
+extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, const float* table,
+                                const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                                void* workspace, float* scores, void* stream) {
+  int rc = common_checks("ultr_dnn_forward", desc, params, table, table_stats, n_rows, ldx, docids, M, workspace);
+  if (rc) return rc;
+  ULTR_REQUIRE(scores, ULTR_EINVAL, "ultr_dnn_forward: null scores");
+  const Layout L = make_layout(desc, M);
+  float* ws = reinterpret_cast<float*>(workspace);
+  const int has_ln = desc->norm == ULTR_NORM_LAYER;
+  hipStream_t st = as_stream(stream);
+  for (int j = 0; j < L.H; ++j) {
+    FwdArgs a{};
+    if (j == 0) {
+      a.x = table; a.ldx = ldx; a.docids = docids; a.n_rows = n_rows; a.row_stats = table_stats;
+    } else {
+      a.x = ws + L.act[j - 1]; a.ldx = L.ldn[j - 1]; a.docids = nullptr; a.n_rows = 0;
+      a.part_in = ws + L.part[j - 1]; a.stat_out = ws + L.stat[j];
+    }
+    a.has_ln = has_ln; a.eps = desc->ln_eps;
+    a.gamma = params + desc->off_gamma[j]; a.beta = params + desc->off_beta[j];
+    a.W = params + desc->off_W[j]; a.bias = params + desc->off_b[j];
+    a.K = L.K[j]; a.N = L.N[j]; a.ldn = L.ldn[j]; a.M = M; a.activation = desc->activation;
+    a.act_out = ws + L.act[j]; a.part_out = ws + L.part[j];
+    hipLaunchKernelGGL(fwd_layer_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.N[j], 128)), dim3(kThreads), 0,
+                       st, a);
+    rc = check_launch("fwd_layer_kernel");
+    if (rc) return rc;
+  }
+  OutArgs o{};
+  const int j = L.H;
+  if (j == 0) {
+    o.x = table; o.ldx = ldx; o.docids = docids; o.n_rows = n_rows; o.row_stats = table_stats;
+  } else {
+    o.x = ws + L.act[j - 1]; o.ldx = L.ldn[j - 1]; o.part_in = ws + L.part[j - 1]; o.stat_out = ws + L.stat[j];
+  }
+  o.has_ln = has_ln; o.eps = desc->ln_eps;
+  o.gamma = params + desc->off_gamma[j]; o.beta = params + desc->off_beta[j];
+  o.W = params + desc->off_W[j]; o.bias = params + desc->off_b[j];
+  o.K = L.K[j]; o.M = M; o.scores = scores;
+  hipLaunchKernelGGL(fwd_out_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, o);
+  return check_launch("fwd_out_kernel");
+}
+
+extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, const float* table,
+                                 const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                                 void* workspace, const float* d_scores, float* grads, void* stream) {
+  int rc = common_checks("ultr_dnn_backward", desc, params, table, table_stats, n_rows, ldx, docids, M, workspace);
+  if (rc) return rc;
+  ULTR_REQUIRE(d_scores && grads && ((uintptr_t)grads & 15) == 0, ULTR_EINVAL, "ultr_dnn_backward: bad d_scores/grads");
+  const Layout L = make_layout(desc, M);
+  float* ws = reinterpret_cast<float*>(workspace);
+  const int has_ln = desc->norm == ULTR_NORM_LAYER;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)desc->n_params, st) != hipSuccess) {
+    set_error("ultr_dnn_backward: hipMemsetAsync failed");
+    return ULTR_EHIP;
+  }
+  const int H = L.H;
+  int cur = 0;  // which dz buffer holds the gradient wrt the current layer's output
+  {
+    BwdOutArgs b{};
+    OutArgs& o = b.f;
+    if (H == 0) {
+      o.x = table; o.ldx = ldx; o.docids = docids; o.n_rows = n_rows; o.row_stats = table_stats;
+    } else {
+      o.x = ws + L.act[H - 1]; o.ldx = L.ldn[H - 1];
+      b.stat_in = ws + L.stat[H];
+    }
+    o.has_ln = has_ln; o.eps = desc->ln_eps;
+    o.gamma = params + desc->off_gamma[H]; o.beta = params + desc->off_beta[H];
+    o.W = params + desc->off_W[H]; o.bias = params + desc->off_b[H];
+    o.K = L.K[H]; o.M = M;
+    b.d_scores = d_scores; b.activation = desc->activation; b.has_prev = H > 0;
+    b.dz = ws + L.dz[cur]; b.lddz = H > 0 ? L.ldn[H - 1] : 0;
+    b.rows_per_block = L.out_rows_per_block; b.partials = ws + L.outpart;
+    const size_t smem = sizeof(float) * 4 * (3 * (size_t)L.K[H] + 1);
+    ULTR_REQUIRE(smem <= 64 * 1024, ULTR_ELIMIT, "ultr_dnn_backward: output layer input width %d too large", L.K[H]);
+    hipLaunchKernelGGL(bwd_out_kernel, dim3((unsigned)L.out_blocks), dim3(kThreads), smem, st, b);
+    rc = check_launch("bwd_out_kernel");
+    if (rc) return rc;
+  }
+  for (int j = H - 1; j >= 0; --j) {
+    WgradArgs g{};
+    if (j == 0) {
+      g.x = table; g.ldx = ldx; g.docids = docids; g.n_rows = n_rows; g.row_stats = table_stats;
+    } else {
+      g.x = ws + L.act[j - 1]; g.ldx = L.ldn[j - 1]; g.stat_in = ws + L.stat[j];
+    }
+    g.has_ln = has_ln;
+    g.dz = ws + L.dz[cur]; g.ldn = L.ldn[j]; g.N = L.N[j];
+    g.K = L.K[j]; g.M = M; g.rows_per_split = L.rows_per_split[j];
+    g.gslab = ws + L.gslab[j]; g.sslab = ws + L.sslab[j];
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64), (unsigned)L.nsplit[j]),
+                       dim3(kThreads), 0, st, g);
+    rc = check_launch("wgrad_kernel");
+    if (rc) return rc;
+    if (j > 0) {
+      DgradArgs d{};
+      d.dz = ws + L.dz[cur]; d.ldn = L.ldn[j]; d.N = L.N[j];
+      d.W = params + desc->off_W[j];
+      d.K = L.K[j]; d.ldk = L.ldn[j - 1]; d.M = M;
+      d.dh = ws + L.dz[cur ^ 1];
+      hipLaunchKernelGGL(dgrad_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128)), dim3(kThreads), 0,
+                         st, d);
+      rc = check_launch("dgrad_kernel");
+      if (rc) return rc;
+      RowpassArgs r{};
+      r.dh = ws + L.dz[cur ^ 1]; r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
+      r.a = ws + L.act[j - 1]; r.stat = ws + L.stat[j]; r.gamma = params + desc->off_gamma[j];
+      r.has_ln = has_ln; r.activation = desc->activation;
+      hipLaunchKernelGGL(rowpass_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, r);
+      rc = check_launch("rowpass_kernel");
+      if (rc) return rc;
+      cur ^= 1;
+    }
+  }
+  FinalizeArgs f{};
+  f.H = H;
+  int start = 0;
+  for (int j = 0; j < H; ++j) {
+    f.row_start[j] = start;
+    start += L.K[j];
+    f.K[j] = L.K[j]; f.N[j] = L.N[j]; f.ldn[j] = L.ldn[j]; f.nsplit[j] = L.nsplit[j];
+    f.gslab[j] = ws + L.gslab[j]; f.sslab[j] = ws + L.sslab[j];
+  }
+  f.row_start[H] = start;
+  for (int j = 0; j <= H; ++j) {
+    f.off_W[j] = desc->off_W[j]; f.off_b[j] = desc->off_b[j];
+    f.off_gamma[j] = desc->off_gamma[j]; f.off_beta[j] = desc->off_beta[j];
+  }
+  f.params = params; f.grads = grads; f.has_ln = has_ln;
+  f.outpart = ws + L.outpart; f.out_blocks = L.out_blocks; f.Kout = L.K[H];
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(start + 1)), dim3(kThreads), 0, st, f);
+  return check_launch("finalize_kernel");
+}

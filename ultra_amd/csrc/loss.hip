@@ -1,0 +1,536 @@
+// Propensity-weighted losses, forward + backward fused, one thread per query list.
+// Reference: ultra/learning_algorithm/base_algorithm.py:136-251 (losses),
+//   dla.py:119-180,257-306,343-364 ; ipw_rank.py:110-143 ; regression_EM.py:116-176 ;
+//   pairwise_debias.py:139-171 ; ultra/utils/propensity_estimator.py:33-42.
+//
+// Layout: scores / clicks / d_scores are position-major [L][B] (element (b,l) at l*B+b), so the
+// 64 lanes of a wave read 64 consecutive floats of one rank: every access is coalesced.
+// Batch sums: per-wave shuffles -> per-block LDS (fixed order) -> per-block partial row in the
+// workspace -> the last block to arrive sums the rows in block order (deterministic).
+#include "common.hpp"
+
+namespace ultr {
+
+constexpr int kLossThreads = 256;
+constexpr int kMaxStat = 4 + 4 * ULTR_MAX_LIST;  // widest partial row (DLA / REM)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|))
+__device__ __forceinline__ float sig_ce(float z, float x) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float clip_w(float w, float maxw) { return maxw > 0.f ? fminf(fmaxf(w, 0.f), maxw) : w; }
+
+// Per-block accumulation of NS batch sums (or maxima) into LDS, fixed order.
+struct BlockStats {
+  float* s_acc;  // [NS]
+  float* s_red;  // [4]
+  __device__ __forceinline__ void add(int slot, float v, bool is_max = false) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) s_red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float r = s_red[0];
+      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, s_red[w]) : r + s_red[w];
+      s_acc[slot] = r;
+    }
+  }
+};
+
+// Publish this block's row, and in the last block reduce all rows into out[0..ns).  Slots >=
+// max_from are reduced with max instead of +.  Returns true in the (single) last block, with the
+// totals also left in s_acc.
+__device__ __forceinline__ bool finish_stats(float* s_acc, int ns, int max_from, float* ws, float* out) {
+  unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
+  float* rows = ws + 8;
+  __syncthreads();
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) rows[(long long)blockIdx.x * ns + s] = s_acc[s];
+  const bool last = last_block_arrive(counter, gridDim.x);
+  if (last) {
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+      float r = rows[s];
+      for (unsigned int b = 1; b < gridDim.x; ++b) {
+        const float v = rows[(long long)b * ns + s];
+        r = (s >= max_from) ? fmaxf(r, v) : r + v;
+      }
+      s_acc[s] = r;
+      out[s] = r;
+    }
+    __syncthreads();
+  }
+  return last;
+}
+
+// ------------------------------------------------------------------------------------------
+// IPW: softmax_loss / sigmoid_loss_on_list with per-element weights
+// stats: [0] numerator  [1] normaliser  [2+l] max_b pw
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLossThreads) ipw_loss_kernel(const float* __restrict__ scores,
+                                                                const float* __restrict__ clicks,
+                                                                const float* __restrict__ pw, int B, int L,
+                                                                int loss_func, float* __restrict__ d_scores,
+                                                                float* __restrict__ stats,
+                                                                float* __restrict__ list_weights, float* ws) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_red[4];
+  BlockStats bs{s_acc, s_red};
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = b < B;
+  float num = 0.f, den = 0.f, lw = 0.f;
+  if (loss_func == ULTR_LOSS_SOFTMAX) {
+    float m = -INFINITY;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, on ? scores[(long long)l * B + b] : 0.f);
+    float se = 0.f, S = 0.f;
+    for (int l = 0; l < L; ++l) {
+      if (!on) break;
+      se += expf(scores[(long long)l * B + b] - m);
+      S += (clicks[(long long)l * B + b] + 0.0000001f) * pw[(long long)l * B + b];
+    }
+    const float lse = m + logf(se);
+    for (int l = 0; l < L; ++l) {
+      if (!on) break;
+      const long long e = (long long)l * B + b;
+      const float o = scores[e], c = clicks[e], w = pw[e];
+      const float wl = (c + 0.0000001f) * w;
+      num -= wl * (o - lse);
+      d_scores[e] = expf(o - lse) * S - wl;
+      lw += w * fminf(fmaxf(c, 0.f), 1.f);
+    }
+    den = on ? S : 0.f;
+  } else {
+    for (int l = 0; l < L; ++l) {
+      if (!on) break;
+      const long long e = (long long)l * B + b;
+      const float o = scores[e], c = clicks[e], w = pw[e];
+      const float z = fminf(c, 1.f);
+      num += sig_ce(z, o) * w;
+      d_scores[e] = (sigmoidf_(o) - z) * w;
+      lw += w * fminf(fmaxf(c, 0.f), 1.f);
+    }
+    den = on ? 1.f : 0.f;
+  }
+  if (on && list_weights) list_weights[b] = lw / (float)L;
+  bs.add(0, num);
+  bs.add(1, den);
+  for (int l = 0; l < L; ++l) bs.add(2 + l, on ? pw[(long long)l * B + b] : -INFINITY, true);
+  finish_stats(s_acc, 2 + L, 2, ws, stats);
+}
+
+__global__ void ipw_weights_kernel(const float* __restrict__ clicks, int B, int L, const float* __restrict__ ipw,
+                                   int n_ipw, float* __restrict__ pw) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)B * L) return;
+  const int l = (int)(e / B);
+  pw[e] = clicks[e] > 0.f ? ipw[l < n_ipw ? l : n_ipw - 1] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// DLA
+// stats: [0] rank num [1] rank den [2] exam num [3] exam den [4+l] pw_l [4+L+l] sum_b rw
+// internal partial row adds [4+2L+l] = column sums needed for d exam/d logit
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
+    const float* __restrict__ scores, const float* __restrict__ clicks, int B, int L,
+    const float* __restrict__ prop_params, int loss_func, int prob_kind, float max_pw,
+    float* __restrict__ d_scores, float* __restrict__ prop_grads, float* __restrict__ list_weights,
+    float* __restrict__ stats, float* ws) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_red[4];
+  __shared__ float s_logit[ULTR_MAX_LIST], s_pre[ULTR_MAX_LIST], s_prob[ULTR_MAX_LIST], s_pw[ULTR_MAX_LIST],
+      s_logp[ULTR_MAX_LIST];
+  BlockStats bs{s_acc, s_red};
+  const int tid = threadIdx.x;
+  // propensity tower: one-hot(position) @ W_0 + b_0 -> ELU  (dla.py:264-304): logit_l = ELU(W[l]+b)
+  if (tid < L) {
+    const float pre = prop_params[tid] + prop_params[L];
+    s_pre[tid] = pre;
+    s_logit[tid] = eluf_(pre);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = -INFINITY, mean = 0.f;
+    for (int l = 0; l < L; ++l) {
+      m = fmaxf(m, s_logit[l]);
+      mean += s_logit[l];
+    }
+    mean /= (float)L;
+    float se = 0.f;
+    for (int l = 0; l < L; ++l) se += expf(s_logit[l] - m);
+    for (int l = 0; l < L; ++l) {
+      s_logp[l] = s_logit[l] - m - logf(se);
+      s_prob[l] = prob_kind == ULTR_PROB_SOFTMAX ? expf(s_logit[l] - m) / se : sigmoidf_(s_logit[l] - mean);
+    }
+    for (int l = 0; l < L; ++l) s_pw[l] = clip_w(s_prob[0] / s_prob[l], max_pw);  // dla.py:352-364
+  }
+  __syncthreads();
+
+  const int b = blockIdx.x * blockDim.x + tid;
+  const bool on = b < B;
+  float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f, lw = 0.f;
+  float m = -INFINITY, mean = 0.f, se = 0.f, S = 0.f, p0 = 1.f;
+  if (on) {
+    for (int l = 0; l < L; ++l) {
+      const float o = scores[(long long)l * B + b];
+      m = fmaxf(m, o);
+      mean += o;
+    }
+    mean /= (float)L;
+    for (int l = 0; l < L; ++l) {
+      const long long e = (long long)l * B + b;
+      se += expf(scores[e] - m);
+      S += (clicks[e] + 0.0000001f) * s_pw[l];
+    }
+    const float o0 = scores[b];
+    p0 = prob_kind == ULTR_PROB_SOFTMAX ? expf(o0 - m) / se : sigmoidf_(o0 - mean);
+  }
+  const float lse = m + logf(se);
+  // the L column sums are block reductions, so every thread walks every l
+  for (int l = 0; l < L; ++l) {
+    float rw = 0.f, col = 0.f;
+    if (on) {
+      const long long e = (long long)l * B + b;
+      const float o = scores[e], c = clicks[e];
+      const float pl = prob_kind == ULTR_PROB_SOFTMAX ? expf(o - m) / se : sigmoidf_(o - mean);
+      rw = clip_w(p0 / pl, max_pw);  // relevance weights (dla.py:159-160)
+      lw += s_pw[l] * fminf(fmaxf(c, 0.f), 1.f);
+      if (loss_func == ULTR_LOSS_SOFTMAX) {
+        const float wl = (c + 0.0000001f) * s_pw[l];
+        rank_num -= wl * (o - lse);
+        d_scores[e] = expf(o - lse) * S - wl;
+        const float wle = (c + 0.0000001f) * rw;
+        exam_num -= wle * s_logp[l];
+        exam_den += wle;
+        col = wle;  // d exam/d logit_l = softmax(logit)_l * sum_b S'_b - sum_b wle
+      } else {
+        const float z = fminf(c, 1.f);
+        rank_num += sig_ce(z, o) * s_pw[l];
+        d_scores[e] = (sigmoidf_(o) - z) * s_pw[l];
+        exam_num += sig_ce(z, s_logit[l]) * rw;
+        col = (sigmoidf_(s_logit[l]) - z) * rw;  // d exam/d logit_l directly
+      }
+    }
+    bs.add(4 + L + l, rw);
+    bs.add(4 + 2 * L + l, col);
+  }
+  if (on) {
+    rank_den = loss_func == ULTR_LOSS_SOFTMAX ? S : 1.f;
+    if (loss_func != ULTR_LOSS_SOFTMAX) exam_den = 1.f;
+    if (list_weights) list_weights[b] = lw / (float)L;
+  }
+  bs.add(0, rank_num);
+  bs.add(1, rank_den);
+  bs.add(2, exam_num);
+  bs.add(3, exam_den);
+  __syncthreads();
+  if (tid < L) s_acc[4 + tid] = 0.f;  // pw_l is batch independent: filled in by the last block
+  if (finish_stats(s_acc, 4 + 3 * L, 1 << 30, ws, stats)) {
+    if (tid < L) stats[4 + tid] = s_pw[tid];
+    // chain through the tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l
+    if (tid == 0) {
+      float db = 0.f;
+      for (int l = 0; l < L; ++l) {
+        float dlogit;
+        if (loss_func == ULTR_LOSS_SOFTMAX) {
+          const float sm = expf(s_logp[l]);
+          dlogit = sm * s_acc[3] - s_acc[4 + 2 * L + l];
+        } else {
+          dlogit = s_acc[4 + 2 * L + l];
+        }
+        const float dpre = dlogit * (s_pre[l] > 0.f ? 1.f : s_logit[l] + 1.f);
+        prop_grads[l] = dpre;
+        db += dpre;
+      }
+      prop_grads[L] = db;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Regression-EM
+// stats: [0] sum loss_b [1] B [2+l] M-step numerator [2+L+l] sum ranker_label [2+2L+l] sum clicks
+//        [2+3L] sum of d_scores (gradient of sigmoid_prob_b, un-normalised)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
+    const float* __restrict__ scores, const float* __restrict__ clicks, int B, int L,
+    const float* __restrict__ propensity, const float* __restrict__ bias_ptr, const float* __restrict__ uniforms,
+    unsigned long long seed, unsigned int step, const unsigned int* step_ctr, unsigned int slot_base,
+    float* __restrict__ d_scores, float* __restrict__ ranker_labels, float* __restrict__ list_weights,
+    float* __restrict__ stats, float* d_bias, float* ws) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_red[4];
+  BlockStats bs{s_acc, s_red};
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = b < B;
+  const float bias = bias_ptr ? bias_ptr[0] : 0.f;
+  if (step_ctr) step += step_ctr[0];  // device-resident step counter (read-only here), see feed.hip
+  float loss = 0.f, lw = 0.f, dsum = 0.f;
+  Philox4 rnd;
+  for (int l = 0; l < L; ++l) {
+    float mstep = 0.f, y = 0.f, c = 0.f;
+    if (on) {
+      const long long e = (long long)l * B + b;
+      const float x = scores[e] + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
+      c = clicks[e];
+      const float p = propensity[l];
+      const float g = sigmoidf_(x);
+      const float den = 1.f - p * g;
+      const float p_e1_r0_c0 = p * (1.f - g) / den;  // :140-141
+      const float p_e0_r1_c0 = (1.f - p) * g / den;  // :142-143
+      const float p_r1 = c + (1.f - c) * p_e0_r1_c0;  // :147-148
+      mstep = c + (1.f - c) * p_e1_r0_c0;             // :153
+      float u;
+      if (uniforms) {
+        u = uniforms[e];
+      } else {
+        if ((l & 3) == 0) rnd = philox4x32_10(slot_base + (uint32_t)b, 0x52454Du, (uint32_t)(l >> 2), step,
+                                             (uint32_t)seed, (uint32_t)(seed >> 32));
+        u = u24(rnd.v[l & 3]);
+      }
+      y = ceilf(p_r1 - u);  // get_bernoulli_sample (:39)
+      y = y > 0.f ? y : 0.f;  // ceil(-0.x) = -0 -> 0
+      loss += sig_ce(y, x);   // :159-165
+      const float d = g - y;
+      d_scores[e] = d;
+      dsum += d;
+      if (ranker_labels) ranker_labels[e] = y;
+      lw += fminf(fmaxf(c, 0.f), 1.f) / p;  // propensity_weights = 1/propensity (:176)
+    }
+    bs.add(2 + l, mstep);
+    bs.add(2 + L + l, y);
+    bs.add(2 + 2 * L + l, c);
+  }
+  if (on && list_weights) list_weights[b] = lw / (float)L;
+  bs.add(0, loss);
+  bs.add(1, on ? 1.f : 0.f);
+  bs.add(2 + 3 * L, dsum);
+  if (finish_stats(s_acc, 3 + 3 * L, 1 << 30, ws, stats)) {
+    if (threadIdx.x == 0 && d_bias) d_bias[0] = s_acc[2 + 3 * L];  // un-normalised d loss / d sigmoid_prob_b
+  }
+}
+
+__global__ void rem_update_kernel(float* propensity, int L, const float* stats, float s, float* old_out) {
+  const int l = threadIdx.x;
+  if (l < L && old_out) old_out[l] = propensity[l];
+  if (l < L) propensity[l] = (1.f - s) * propensity[l] + s * (stats[2 + l] / stats[1]);  // regression_EM.py:151-155
+}
+
+// ------------------------------------------------------------------------------------------
+// Pairwise debiasing.  The block's [L][256] tile of scores and clicks is staged in LDS; every
+// (i, j) pair is then evaluated from LDS.  stats: [i*L+j] pair loss l_ij, [L*L] loss.
+// ------------------------------------------------------------------------------------------
+constexpr int kPdMaxL = 32;
+
+__global__ void __launch_bounds__(kLossThreads) pd_loss_kernel(const float* __restrict__ scores,
+                                                               const float* __restrict__ clicks, int B, int L,
+                                                               const float* __restrict__ t_plus,
+                                                               const float* __restrict__ t_minus,
+                                                               float* __restrict__ d_scores, float* __restrict__ stats,
+                                                               float* ws) {
+  extern __shared__ float smem[];
+  float* s_o = smem;                         // [L][256]
+  float* s_c = smem + L * kLossThreads;      // [L][256]
+  float* s_acc = s_c + L * kLossThreads;     // [L*L+1]
+  float* s_wave = s_acc + (L * L + 1);       // [4][L*L]
+  __shared__ float s_tp[kPdMaxL], s_tm[kPdMaxL];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x * blockDim.x + tid;
+  const bool on = b < B;
+  for (int l = 0; l < L; ++l) {
+    s_o[l * kLossThreads + tid] = on ? scores[(long long)l * B + b] : 0.f;
+    s_c[l * kLossThreads + tid] = on ? clicks[(long long)l * B + b] : 0.f;
+  }
+  if (tid < L) {
+    s_tp[tid] = t_plus[tid];
+    s_tm[tid] = t_minus[tid];
+  }
+  for (int s = tid; s < 4 * L * L; s += blockDim.x) s_wave[s] = 0.f;
+  __syncthreads();
+  // pair losses: l_ij = sum_b min(1, relu(c_i - c_j)) * softplus(o_j - o_i)   (:147-155)
+  for (int i = 0; i < L; ++i) {
+    const float ci = s_c[i * kLossThreads + tid], oi = s_o[i * kLossThreads + tid];
+    if (!__any(ci > 0.f)) continue;  // wave-uniform skip: no clicked doc at rank i in these 64 lists
+    for (int j = 0; j < L; ++j) {
+      if (j == i) continue;
+      const float mask = fminf(1.f, fmaxf(ci - s_c[j * kLossThreads + tid], 0.f));
+      float v = 0.f;
+      if (mask > 0.f) {
+        const float diff = s_o[j * kLossThreads + tid] - oi;
+        v = mask * (fmaxf(diff, 0.f) + log1pf(expf(-fabsf(diff))));
+      }
+      v = wave_sum(v);
+      if (lane == 0) s_wave[wid * L * L + i * L + j] = v;
+    }
+  }
+  // gradient wrt o_k: -sum_j w_kj sig(o_j-o_k) + sum_i w_ik sig(o_k-o_i), w_ij = mask_ij/(t+_i t-_j)
+  if (on) {
+    for (int k = 0; k < L; ++k) {
+      const float ck = s_c[k * kLossThreads + tid], ok = s_o[k * kLossThreads + tid];
+      float acc = 0.f;
+      for (int j = 0; j < L; ++j) {
+        if (j == k) continue;
+        const float cj = s_c[j * kLossThreads + tid];
+        const float m1 = fminf(1.f, fmaxf(ck - cj, 0.f));
+        const float m2 = fminf(1.f, fmaxf(cj - ck, 0.f));
+        if (m1 > 0.f || m2 > 0.f) {
+          const float sg = sigmoidf_(s_o[j * kLossThreads + tid] - ok);  // d softplus(o_j - o_k)
+          acc -= m1 / (s_tp[k] * s_tm[j]) * sg;
+          acc += m2 / (s_tp[j] * s_tm[k]) * (1.f - sg);  // sig(o_k - o_j)
+        }
+      }
+      d_scores[(long long)k * B + b] = acc;
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < L * L; s += blockDim.x)
+    s_acc[s] = s_wave[s] + s_wave[L * L + s] + s_wave[2 * L * L + s] + s_wave[3 * L * L + s];
+  if (tid == 0) s_acc[L * L] = 0.f;
+  if (finish_stats(s_acc, L * L + 1, 1 << 30, ws, stats)) {
+    if (tid == 0) {  // loss = sum_ij l_ij / t+_i / t-_j  (:158-159), pre-update ratios
+      float loss = 0.f;
+      for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j)
+          if (i != j) loss += s_acc[i * L + j] / s_tp[i] / s_tm[j];
+      stats[L * L] = loss;
+    }
+  }
+}
+
+// t+_i <- (1-s) t+_i + s (A_i/A_0)^(1/(p+1)), A_i = sum_j l_ij/t-_j ; t-_j likewise (:162-171)
+__global__ void pd_update_kernel(float* t_plus, float* t_minus, int L, float* stats, float s, float reg_p,
+                                 float* old_out) {
+  __shared__ float A[kPdMaxL], Am[kPdMaxL], tp[kPdMaxL], tm[kPdMaxL];
+  const int k = threadIdx.x;
+  if (k < L) {
+    tp[k] = t_plus[k];
+    tm[k] = t_minus[k];
+    if (old_out) {
+      old_out[k] = tp[k];
+      old_out[L + k] = tm[k];
+    }
+  }
+  __syncthreads();
+  if (k < L) {
+    float a = 0.f, am = 0.f;
+    for (int j = 0; j < L; ++j) {
+      if (j == k) continue;
+      a += stats[k * L + j] / tm[j];   // t_plus_loss_list[k]
+      am += stats[j * L + k] / tp[j];  // t_minus_loss_list[k]
+    }
+    A[k] = a;
+    Am[k] = am;
+  }
+  __syncthreads();
+  if (k < L) {
+    const float e = 1.f / (reg_p + 1.f);
+    t_plus[k] = (1.f - s) * tp[k] + s * powf(A[k] / A[0], e);
+    t_minus[k] = (1.f - s) * tm[k] + s * powf(Am[k] / Am[0], e);
+  }
+  if (k == 0) {  // loss with the all-reduced pair matrix (data-parallel runs recompute it here)
+    float loss = 0.f;
+    for (int i = 0; i < L; ++i)
+      for (int j = 0; j < L; ++j)
+        if (i != j) loss += stats[i * L + j] / tp[i] / tm[j];
+    stats[L * L] = loss;
+  }
+}
+
+}  // namespace ultr
+
+using namespace ultr;
+
+extern "C" long long ultr_loss_workspace_floats(int B, int L) {
+  const long long blocks = cdiv(B > 0 ? B : 1, kLossThreads);
+  long long ns = 4 + 4 * (long long)L;
+  if ((long long)L * L + 1 > ns) ns = (long long)L * L + 1;
+  return 8 + blocks * ns;
+}
+
+static int loss_args_ok(const char* who, const void* scores, const void* clicks, int B, int L, const void* ws) {
+  ULTR_REQUIRE(scores && clicks && ws, ULTR_EINVAL, "%s: null pointer", who);
+  ULTR_REQUIRE(B > 0 && L > 0, ULTR_EINVAL, "%s: bad sizes B=%d L=%d", who, B, L);
+  ULTR_REQUIRE(L <= ULTR_MAX_LIST, ULTR_ELIMIT, "%s: L=%d > %d", who, L, ULTR_MAX_LIST);
+  return ULTR_OK;
+}
+
+extern "C" int ultr_loss_ipw_fwdbwd(const float* scores, const float* clicks, const float* pw, int B, int L,
+                                    int loss_func, float* d_scores, float* stats, float* list_weights, float* ws,
+                                    void* stream) {
+  int rc = loss_args_ok("ultr_loss_ipw_fwdbwd", scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(pw && d_scores && stats, ULTR_EINVAL, "ultr_loss_ipw_fwdbwd: null pointer");
+  ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
+               "ultr_loss_ipw_fwdbwd: loss_func=%d (pairwise_loss raises NameError in the reference and is not "
+               "supported)", loss_func);
+  hipLaunchKernelGGL(ipw_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
+                     scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
+  return check_launch("ipw_loss_kernel");
+}
+
+extern "C" int ultr_ipw_weights(const float* clicks, int B, int L, const float* ipw, int n_ipw, float* pw,
+                                void* stream) {
+  ULTR_REQUIRE(clicks && ipw && pw && B > 0 && L > 0 && n_ipw > 0, ULTR_EINVAL, "ultr_ipw_weights: bad argument");
+  hipLaunchKernelGGL(ipw_weights_kernel, dim3((unsigned)cdiv((long long)B * L, 256)), dim3(256), 0, as_stream(stream),
+                     clicks, B, L, ipw, n_ipw, pw);
+  return check_launch("ipw_weights_kernel");
+}
+
+extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* prop_params,
+                                    int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
+                                    float* prop_grads, float* list_weights, float* stats, float* ws, void* stream) {
+  int rc = loss_args_ok("ultr_loss_dla_fwdbwd", scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(prop_params && d_scores && prop_grads && stats, ULTR_EINVAL, "ultr_loss_dla_fwdbwd: null pointer");
+  ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
+               "ultr_loss_dla_fwdbwd: loss_func=%d not supported", loss_func);
+  ULTR_REQUIRE(logits_to_prob == ULTR_PROB_SOFTMAX || logits_to_prob == ULTR_PROB_SIGMOID, ULTR_EINVAL,
+               "ultr_loss_dla_fwdbwd: logits_to_prob=%d", logits_to_prob);
+  hipLaunchKernelGGL(dla_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
+                     scores, clicks, B, L, prop_params, loss_func, logits_to_prob, max_propensity_weight, d_scores,
+                     prop_grads, list_weights, stats, ws);
+  return check_launch("dla_loss_kernel");
+}
+
+extern "C" int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* propensity,
+                                    const float* sigmoid_prob_b, const float* uniforms, unsigned long long seed,
+                                    unsigned int step, const unsigned int* step_ctr, unsigned int slot_base,
+                                    float* d_scores, float* ranker_labels, float* list_weights,
+                                    float* stats, float* d_bias, float* ws, void* stream) {
+  int rc = loss_args_ok("ultr_loss_rem_fwdbwd", scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(propensity && d_scores && stats, ULTR_EINVAL, "ultr_loss_rem_fwdbwd: null pointer");
+  hipLaunchKernelGGL(rem_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
+                     scores, clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base, d_scores,
+                     ranker_labels, list_weights, stats, d_bias, ws);
+  return check_launch("rem_loss_kernel");
+}
+
+extern "C" int ultr_rem_update_propensity(float* propensity, int L, const float* stats, float em_step_size,
+                                          float* old_out, void* stream) {
+  ULTR_REQUIRE(propensity && stats && L > 0 && L <= ULTR_MAX_LIST, ULTR_EINVAL, "ultr_rem_update_propensity: bad args");
+  hipLaunchKernelGGL(rem_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), propensity, L, stats, em_step_size, old_out);
+  return check_launch("rem_update_kernel");
+}
+
+extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* t_plus,
+                                   const float* t_minus, float* d_scores, float* stats, float* ws, void* stream) {
+  int rc = loss_args_ok("ultr_loss_pd_fwdbwd", scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(t_plus && t_minus && d_scores && stats, ULTR_EINVAL, "ultr_loss_pd_fwdbwd: null pointer");
+  ULTR_REQUIRE(L <= kPdMaxL, ULTR_ELIMIT, "ultr_loss_pd_fwdbwd: L=%d > %d", L, kPdMaxL);
+  const size_t smem = sizeof(float) * ((size_t)2 * L * kLossThreads + (size_t)L * L + 1 + (size_t)4 * L * L);
+  if (smem > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pd_loss_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(pd_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), smem,
+                     as_stream(stream), scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws);
+  return check_launch("pd_loss_kernel");
+}
+
+extern "C" int ultr_pd_update_ratios(float* t_plus, float* t_minus, int L, float* stats, float em_step_size,
+                                     float regulation_p, float* old_out, void* stream) {
+  ULTR_REQUIRE(t_plus && t_minus && stats && L > 0 && L <= kPdMaxL, ULTR_EINVAL, "ultr_pd_update_ratios: bad args");
+  hipLaunchKernelGGL(pd_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), t_plus, t_minus, L, stats,
+                     em_step_size, regulation_p, old_out);
+  return check_launch("pd_update_kernel");
+}

@@ -1,0 +1,158 @@
+// Global-norm clip + Adagrad / SGD over a flat fp32 parameter buffer.
+// Reference: tf.clip_by_global_norm + tf.train.AdagradOptimizer.apply_gradients as used in
+//   dla.py:240-255, ipw_rank.py:155-165, regression_EM.py:188-194, pairwise_debias.py:185-191.
+// TF semantics restated: clip: g * clip/max(||g||, clip); Adagrad: acc += g^2 (acc0 = 0.1),
+// theta -= lr * g / sqrt(acc), no epsilon; tf.nn.l2_loss(p) = sum(p^2)/2 so its gradient is p.
+//
+// HBM-bound: 20 B per parameter per step (read g, acc, theta; write acc, theta) + 8 B for the
+// norm pass (g, theta re-read, L2-resident for the DNN's <= 2 MB of parameters).
+#include "common.hpp"
+
+namespace ultr {
+
+constexpr int kOptThreads = 256;
+constexpr int kOptMaxBlocks = 1024;
+
+__device__ __forceinline__ float eff_scale(const float* denom, float scale_const) {
+  return denom ? scale_const / denom[0] : scale_const;
+}
+
+__global__ void __launch_bounds__(kOptThreads) gnorm_partial_kernel(const float* __restrict__ theta,
+                                                                    const float* __restrict__ grads, long long n,
+                                                                    const float* __restrict__ denom, float scale_const,
+                                                                    float l2, float* __restrict__ ws) {
+  __shared__ float red[4];
+  const float sc = eff_scale(denom, scale_const);
+  float acc[1] = {0.f};
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(grads);
+  const float4* t4 = reinterpret_cast<const float4*>(theta);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 g = g4[i];
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l2 != 0.f) t = t4[i];
+    const float a = g.x * sc + l2 * t.x, b = g.y * sc + l2 * t.y, c = g.z * sc + l2 * t.z, d = g.w * sc + l2 * t.w;
+    acc[0] += a * a + b * b + c * c + d * d;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float a = grads[i] * sc + (l2 != 0.f ? l2 * theta[i] : 0.f);
+    acc[0] += a * a;
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) ws[8 + blockIdx.x] = acc[0];
+}
+
+__global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __restrict__ theta, float* __restrict__ accum,
+                                                                    const float* __restrict__ grads, long long n,
+                                                                    const float* __restrict__ denom, float scale_const,
+                                                                    float l2, float clip_norm, float lr, int strategy,
+                                                                    int n_partials, float* __restrict__ out_norm,
+                                                                    const float* __restrict__ ws) {
+  __shared__ float s_factor;
+  if (threadIdx.x == 0) {
+    float ss = 0.f;
+    for (int p = 0; p < n_partials; ++p) ss += ws[8 + p];  // fixed order: every block gets the same norm
+    const float nrm = sqrtf(ss);
+    if (blockIdx.x == 0 && out_norm) out_norm[0] = nrm;
+    s_factor = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
+  }
+  __syncthreads();
+  const float sc = eff_scale(denom, scale_const);
+  const float f = s_factor;
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(grads);
+  float4* t4 = reinterpret_cast<float4*>(theta);
+  float4* a4 = reinterpret_cast<float4*>(accum);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 g = g4[i];
+    float4 t = t4[i];
+    float gv[4] = {g.x, g.y, g.z, g.w};
+    float tv[4] = {t.x, t.y, t.z, t.w};
+    if (strategy == ULTR_OPT_ADAGRAD) {
+      float4 a = a4[i];
+      float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float gq = (gv[q] * sc + l2 * tv[q]) * f;
+        av[q] += gq * gq;
+        tv[q] -= lr * gq / sqrtf(av[q]);
+      }
+      a4[i] = make_float4(av[0], av[1], av[2], av[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tv[q] -= lr * (gv[q] * sc + l2 * tv[q]) * f;
+    }
+    t4[i] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float gq = (grads[i] * sc + l2 * theta[i]) * f;
+    if (strategy == ULTR_OPT_ADAGRAD) {
+      const float a = accum[i] + gq * gq;
+      accum[i] = a;
+      theta[i] -= lr * gq / sqrtf(a);
+    } else {
+      theta[i] -= lr * gq;
+    }
+  }
+}
+
+// n <= 4096 (DLA's propensity tower: L+1 floats): norm and update in one single-block launch
+__global__ void __launch_bounds__(kOptThreads) clip_adagrad_small_kernel(float* theta, float* accum, const float* grads,
+                                                                         int n, const float* denom, float scale_const,
+                                                                         float l2, float clip_norm, float lr,
+                                                                         int strategy, float* out_norm) {
+  __shared__ float red[4];
+  const float sc = eff_scale(denom, scale_const);
+  float ss[1] = {0.f};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float g = grads[i] * sc + l2 * theta[i];
+    ss[0] += g * g;
+  }
+  block_sum<1>(ss, red);
+  const float nrm = sqrtf(ss[0]);
+  if (threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
+  const float f = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float g = (grads[i] * sc + l2 * theta[i]) * f;
+    if (strategy == ULTR_OPT_ADAGRAD) {
+      const float a = accum[i] + g * g;
+      accum[i] = a;
+      theta[i] -= lr * g / sqrtf(a);
+    } else {
+      theta[i] -= lr * g;
+    }
+  }
+}
+
+}  // namespace ultr
+
+using namespace ultr;
+
+extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                                 float scale_const, float l2, float clip_norm, float lr, int strategy,
+                                 float* out_norm, float* ws, void* stream) {
+  ULTR_REQUIRE(theta && grads && n > 0, ULTR_EINVAL, "ultr_clip_adagrad: bad argument");
+  ULTR_REQUIRE(strategy == ULTR_OPT_ADAGRAD || strategy == ULTR_OPT_SGD, ULTR_EINVAL,
+               "ultr_clip_adagrad: grad_strategy=%d", strategy);
+  ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
+  if (n <= 4096) {
+    hipLaunchKernelGGL(clip_adagrad_small_kernel, dim3(1), dim3(kOptThreads), 0, as_stream(stream), theta, acc, grads,
+                       (int)n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm);
+    return check_launch("clip_adagrad_small_kernel");
+  }
+  ULTR_REQUIRE(ws, ULTR_EINVAL, "ultr_clip_adagrad: workspace required");
+  ULTR_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grads % 16 == 0) && (!acc || (uintptr_t)acc % 16 == 0),
+               ULTR_EINVAL, "ultr_clip_adagrad: buffers must be 16-byte aligned");
+  long long blocks = cdiv(n >> 2, kOptThreads);
+  if (blocks > kOptMaxBlocks) blocks = kOptMaxBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta,
+                     grads, n, denom, scale_const, l2, ws);
+  int rc = check_launch("gnorm_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta, acc,
+                     grads, n, denom, scale_const, l2, clip_norm, lr, strategy, (int)blocks, out_norm, ws);
+  return check_launch("adagrad_apply_kernel");
+}

@@ -1,0 +1,354 @@
+"""Plugin base class for the unbiased learning-to-rank algorithms, MI355X edition.
+
+Reference: ultra/learning_algorithm/base_algorithm.py -- abstract API :27-62,
+remove_padding_for_metric_eval :64-87, ranking_model/get_ranking_scores :89-134, losses :136-251.
+The constructor / ``step(session, input_feed, forward_only)`` contract is unchanged; ``session``
+is opaque (pass None).  Where the reference builds a TF graph, this class owns device buffers and
+launches the HIP kernels of libultr_hip.so on torch's current stream:
+
+    feed tensors -> ultr_dnn_forward -> ultr_loss_*_fwdbwd -> ultr_dnn_backward
+                 -> [one RCCL all-reduce of the flat bucket] -> ultr_clip_adagrad -> ultr_metrics
+
+The ``bucket`` is one flat fp32 buffer [ranker grads | additive statistics | local values]; the
+first two parts are what a data-parallel run all-reduces (SUM) once per step, so normalisers, EM
+statistics and gradients are combined before any division -- N ranks x B lists equal one rank x
+N*B lists.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils import data_utils, find_class, hparams as hp, metrics as dev_metrics
+from ..ranking_model.DNN import feature_row_stats
+
+
+class Placeholder(object):
+    """Stands in for a tf.placeholder: the feeds only use ``.name`` as the feed-dict key."""
+
+    def __init__(self, name):
+        self.name = name + ':0'
+
+
+class HostVariable(object):
+    """Stands in for a non-trainable tf.Variable read with ``.eval()`` (main.py:143,149)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def eval(self, session=None):
+        return self.value
+
+
+class Saver(object):
+    """Checkpointing in place of tf.train.Saver (dla.py:222, main.py:68-74,181-194): torch.save of the
+    algorithm's flat buffers.  The TF checkpoint format is not reproduced."""
+
+    def __init__(self, algo):
+        self.algo = algo
+
+    def save(self, session, path, global_step=None):
+        step = global_step.eval() if hasattr(global_step, 'eval') else global_step
+        full = '%s-%s' % (path, step) if step is not None else path
+        torch.save(self.algo.state_dict(), full + '.pt')
+        return full
+
+    def restore(self, session, path):
+        self.algo.load_state_dict(torch.load(path if path.endswith('.pt') else path + '.pt', weights_only=True))
+
+
+class DeviceScalar(object):
+    """A step result that stays on the GPU until somebody looks at it (float(), arithmetic, format)."""
+
+    def __init__(self, fetch):
+        self._fetch, self._v = fetch, None
+
+    def __float__(self):
+        if self._v is None:
+            self._v = float(self._fetch())
+            self._fetch = None
+        return self._v
+
+    item = __float__
+
+    def __add__(self, o): return float(self) + o
+    __radd__ = __add__
+    def __sub__(self, o): return float(self) - o
+    def __rsub__(self, o): return o - float(self)
+    def __mul__(self, o): return float(self) * o
+    __rmul__ = __mul__
+    def __truediv__(self, o): return float(self) / o
+    def __rtruediv__(self, o): return o / float(self)
+    def __eq__(self, o): return float(self) == o
+    def __lt__(self, o): return float(self) < o
+    def __gt__(self, o): return float(self) > o
+    def __format__(self, spec): return format(float(self), spec)
+    def __repr__(self): return repr(float(self))
+
+
+class DeviceBatch(object):
+    """The feed of one step, resident on the device."""
+    __slots__ = ('table', 'table_stats', 'n_rows', 'docids', 'labels', 'B', 'L')
+
+    def __init__(self, table, table_stats, n_rows, docids, labels):
+        self.table, self.table_stats, self.n_rows = table, table_stats, n_rows
+        self.docids, self.labels = docids, labels
+        self.L, self.B = docids.shape
+
+
+DEVICE_BATCH_KEY = 'ultra_amd:device_batch'
+
+
+class BaseAlgorithm(ABC):
+    PADDING_SCORE = -100000
+
+    @abstractmethod
+    def __init__(self, data_set, exp_settings, forward_only=False):
+        pass
+
+    @abstractmethod
+    def step(self, session, input_feed, forward_only):
+        """-> (loss, None, summary) when training, (None, scores [B, max_candidate_num], summary) otherwise."""
+        pass
+
+    # ---- shared construction ---------------------------------------------------------------
+    def _setup(self, data_set, exp_settings, forward_only, hparams):
+        print(exp_settings['learning_algorithm_hparams'])
+        hparams.parse(exp_settings['learning_algorithm_hparams'])
+        self.hparams = hparams
+        self.exp_settings = exp_settings
+        self.forward_only = forward_only
+        self.max_candidate_num = exp_settings['max_candidate_num']
+        self.feature_size = data_set.feature_size
+        self.rank_list_size = None if forward_only else exp_settings['selection_bias_cutoff']
+        if not torch.cuda.is_available():
+            raise _lib.UltrError('ultra_amd needs an MI355X (HIP) device: there is no CPU path')
+        _lib.lib()
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        # feed-dict keys (dla.py:85-94)
+        self.is_training = Placeholder('is_train')
+        self.letor_features = Placeholder('letor_features')
+        self.docid_inputs = [Placeholder('docid_input%d' % i) for i in range(self.max_candidate_num)]
+        self.labels = [Placeholder('label%d' % i) for i in range(self.max_candidate_num)]
+        self.learning_rate = HostVariable(float(hparams.learning_rate))
+        self.global_step = HostVariable(0)
+        # the ranking model, by dotted name (base_algorithm.py:125-128)
+        name = exp_settings['ranking_model']
+        if name.startswith('ultra.'):  # the reference's own settings files select the drop-in class
+            name = 'ultra_amd.' + name[len('ultra.'):]
+        self.model = find_class(name)(exp_settings['ranking_model_hparams'])
+        self.model.create_variables(self.feature_size, self.device, seed=exp_settings.get('seed'))
+        self.n_params = int(self.model.desc.n_params)   # what the DNN kernels see
+        self.n_total = int(self.model.n_total)          # + the spare tail for extra trainables
+        self.n_stats = self._n_stats()
+        self.eval_plan = dev_metrics.MetricPlan(exp_settings['metrics'], exp_settings['metrics_topn'])
+        self.train_plan = self.eval_plan
+        self.shuffle_ties = bool(exp_settings.get('metric_shuffle_ties', False))
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and \
+            torch.distributed.is_initialized() else 1
+        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        self._eval_bufs = {}
+        self._train_bufs = None
+        self.saver = Saver(self)
+        if not forward_only:
+            if hparams.grad_strategy == 'sgd':
+                self.strategy = _lib.OPT_SGD
+                self.acc = None
+            else:
+                self.strategy = _lib.OPT_ADAGRAD
+                self.acc = torch.full((self.n_total,), 0.1, dtype=torch.float32, device=self.device)
+            self.opt_ws = torch.zeros(2048, dtype=torch.float32, device=self.device)
+
+    # ---- feed handling ------------------------------------------------------------------------
+    def _to_device_batch(self, input_feed, list_size):
+        """Accept the device feed of ultra_amd.input_layer as is, or a reference-style feed of numpy
+        arrays (click_simulation_feed.py:158-162: float64 features, float32-typed doc ids, q1)."""
+        batch = input_feed.get(DEVICE_BATCH_KEY)
+        if batch is not None:
+            if batch.L == list_size:
+                return batch
+            return DeviceBatch(batch.table, batch.table_stats, batch.n_rows, batch.docids[:list_size],
+                               batch.labels[:list_size])
+        feats = input_feed[self.letor_features.name]
+        if not torch.is_tensor(feats):
+            feats = torch.as_tensor(np.asarray(feats, dtype=np.float32).reshape(-1, self.feature_size))
+        n_rows = feats.shape[0]
+        ldx = (self.feature_size + 3) // 4 * 4
+        table = torch.zeros((max(n_rows, 1), ldx), dtype=torch.float32, device=self.device)
+        if n_rows:
+            table[:n_rows, :self.feature_size] = feats.to(self.device, torch.float32)
+        table = table[:n_rows] if n_rows else table[:0]
+        stats = feature_row_stats(table, self.feature_size) if self.model.desc.norm == _lib.NORM_LAYER else None
+
+        def stack(placeholders, dtype):
+            cols = [torch.as_tensor(np.asarray(input_feed[p.name])) if not torch.is_tensor(input_feed[p.name])
+                    else input_feed[p.name] for p in placeholders[:list_size]]
+            return torch.stack([c.to(self.device) for c in cols], dim=0).to(dtype).contiguous()
+        return DeviceBatch(table, stats, n_rows, stack(self.docid_inputs, torch.int32),
+                           stack(self.labels, torch.float32))
+
+    # ---- reference helper API ------------------------------------------------------------------
+    def ranking_model(self, list_size, batch, out=None):
+        """Scores of the first ``list_size`` positions, position-major [list_size, B]
+        (base_algorithm.py:89-134: zero pad row, per-position gather, model.build, concat)."""
+        return self.model.forward_lists(batch.table, batch.table_stats, batch.n_rows, batch.docids[:list_size], out)
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    N_LOCAL = 192                               # non-additive values (norms, pre-update EM state)
+
+    def _n_stats(self):
+        """Floats of additive statistics the loss kernel produces (multiple of 4)."""
+        return 4 + 4 * _lib.ULTR_MAX_LIST + 64
+
+    def _train_buffers(self, B):
+        tb = self._train_bufs
+        if tb is not None and tb['B'] == B:
+            return tb
+        L, dev = self.rank_list_size, self.device
+        n_met = self.train_plan.n_out
+        n0, n1 = self.n_total, self.n_total + self.n_stats
+        n_bucket = n1 + n_met + self.N_LOCAL
+        tb = {'B': B}
+        tb['bucket'] = torch.zeros(n_bucket, dtype=torch.float32, device=dev)
+        tb['grads'] = tb['bucket'][:n0]
+        tb['stats'] = tb['bucket'][n0:n1]
+        tb['metrics'] = tb['bucket'][n1:n1 + n_met]
+        tb['local'] = tb['bucket'][n1 + n_met:]
+        tb['n_reduce'] = n1 + n_met
+        tb['scores'] = torch.empty((L, B), dtype=torch.float32, device=dev)
+        tb['d_scores'] = torch.empty((L, B), dtype=torch.float32, device=dev)
+        tb['list_weights'] = torch.empty(B, dtype=torch.float32, device=dev)
+        tb['loss_ws'] = torch.zeros(_lib.lib().ultr_loss_workspace_floats(B, L), dtype=torch.float32, device=dev)
+        tb['met_ws'] = dev_metrics.metrics_workspace(B, self.train_plan, dev)
+        n_host = self.n_stats + n_met + self.N_LOCAL
+        tb['host'] = torch.zeros((64, n_host), dtype=torch.float32).pin_memory()
+        tb['events'] = [None] * 64
+        tb['slot'] = 0
+        tb['fixed_slot'] = getattr(self, '_fixed_slot_default', False)
+        self._train_bufs = tb
+        return tb
+
+    def _all_reduce(self, tb):
+        if self.world > 1:
+            torch.distributed.all_reduce(tb['bucket'][:tb['n_reduce']])
+
+    def _train_metrics(self, tb, batch, scores, weighted):
+        u = None
+        if self.shuffle_ties:
+            u = torch.rand((batch.B, scores.shape[0]), dtype=torch.float32, device=self.device)
+        dev_metrics.batch_metrics(self.train_plan, scores, batch.labels, batch.docids, batch.n_rows,
+                                  tb['list_weights'] if weighted else None, tb['metrics'], tb['met_ws'], u)
+
+    def _publish(self, tb):
+        """Async copy of [stats | metrics | local] to a pinned ring slot; returns fetch() -> numpy row."""
+        slot = 0 if tb['fixed_slot'] else tb['slot']
+        tb['slot'] = (tb['slot'] + 1) % 64
+        host = tb['host'][slot]
+        host.copy_(tb['bucket'][self.n_total:], non_blocking=True)
+        capturing = torch.cuda.is_current_stream_capturing()
+        ev = None
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+        stamp = tb['slot']
+
+        def fetch():
+            if ev is not None:
+                ev.synchronize()
+            else:
+                torch.cuda.current_stream().synchronize()
+            return host.numpy().copy()
+        fetch.stamp = stamp
+        return fetch
+
+    # ---- training step skeleton -------------------------------------------------------------------
+    WEIGHTED_METRICS = True
+
+    def _train_step(self, input_feed):
+        L = self.rank_list_size
+        batch = self._to_device_batch(input_feed, L)
+        tb = self._train_buffers(batch.B)
+        scores = self.ranking_model(L, batch, tb['scores'])
+        self._loss(tb, batch, scores)                          # d_scores + additive statistics
+        self.model.backward(tb['d_scores'], tb['grads'])       # flat un-normalised gradient
+        self._all_reduce(tb)                                   # DP: one collective per step
+        self._update(tb, batch)                                # EM state, clip + Adagrad
+        self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS)
+        fetch = self._publish(tb)
+        self.global_step.value += 1
+        n_stats, n_met, world = self.n_stats, self.train_plan.n_out, float(self.world)
+        tags = self.train_plan.tags(self.WEIGHTED_METRICS)
+        cache = {}
+
+        def row():
+            if 'r' not in cache:
+                r = fetch()
+                cache['r'] = (r[:n_stats], r[n_stats:n_stats + n_met] / world, r[n_stats + n_met:])
+            return cache['r']
+
+        def summary():
+            stats, met, local = row()
+            out = self._summary(stats, local, batch.B * self.world)
+            for tag, slot in tags:
+                out[tag] = met[slot]
+            return out
+        loss = DeviceScalar(lambda: self._loss_value(*row()[0:3:2]))
+        return loss, None, data_utils.Summary(fetch=summary)
+
+    # ---- evaluation step (shared by every algorithm; dla.py:103-115,329-341) -------------------------
+    def _eval_step(self, input_feed):
+        Lx = self.max_candidate_num
+        batch = self._to_device_batch(input_feed, Lx)
+        B = batch.B
+        eb = self._eval_bufs.get(B)
+        if eb is None:
+            eb = {'scores': torch.empty((Lx, B), dtype=torch.float32, device=self.device),
+                  'out': torch.zeros(self.eval_plan.n_out, dtype=torch.float32, device=self.device),
+                  'ws': dev_metrics.metrics_workspace(B, self.eval_plan, self.device)}
+            self._eval_bufs[B] = eb
+        scores = self.ranking_model(Lx, batch, eb['scores'])
+        u = torch.rand((B, Lx), dtype=torch.float32, device=self.device) if self.shuffle_ties else None
+        dev_metrics.batch_metrics(self.eval_plan, scores, batch.labels, batch.docids, batch.n_rows, None, eb['out'],
+                                  eb['ws'], u)
+        out = eb['out'].clone()
+        tags = self.eval_plan.tags(False)
+
+        def fetch():
+            vals = out.cpu().numpy()
+            return {tag: vals[slot] for tag, slot in tags}
+        return None, scores.t().contiguous().cpu().numpy(), data_utils.Summary(fetch=fetch)
+
+    # ---- optimiser helper --------------------------------------------------------------------------
+    def _clip_adagrad(self, theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, out_norm):
+        _lib.check(_lib.lib().ultr_clip_adagrad(
+            _lib.ptr(theta), _lib.ptr(acc), _lib.ptr(grads), int(n), _lib.ptr(denom), float(scale_const), float(l2),
+            float(clip_norm), float(lr), self.strategy, _lib.ptr(out_norm), _lib.ptr(self.opt_ws),
+            _lib.current_stream()), 'ultr_clip_adagrad')
+
+    # ---- checkpoint state ---------------------------------------------------------------------------
+    def state_dict(self):
+        sd = {'params': self.model.params.clone(), 'global_step': torch.tensor(self.global_step.value)}
+        if getattr(self, 'acc', None) is not None:
+            sd['acc'] = self.acc.clone()
+        for k, v in self._extra_state().items():
+            sd[k] = v.clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        self.model.params.copy_(sd['params'])
+        self.global_step.value = int(sd['global_step'])
+        if 'acc' in sd and getattr(self, 'acc', None) is not None:
+            self.acc.copy_(sd['acc'])
+        for k, v in self._extra_state().items():
+            if k in sd:
+                v.copy_(sd[k])
+
+    def _extra_state(self):
+        return {}
+
+    def enable_graph_replay(self, flag=True):
+        """Under hipGraph capture the result row must land in ONE pinned slot (replays reuse addresses)."""
+        if self._train_bufs is not None:
+            self._train_bufs['fixed_slot'] = flag
+        self._fixed_slot_default = flag

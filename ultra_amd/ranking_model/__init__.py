@@ -1,0 +1,2 @@
+from .base_ranking_model import BaseRankingModel, ActivationFunctions, NormalizationFunctions, Initializer
+from .DNN import DNN
