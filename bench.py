@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train query-lists/sec of the ULTRA training step (DNN + DLA, MSLR-WEB10K shape).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
+ClickSimulationFeed.get_batch (device click simulation + batch assembly) -> DLA.step (DNN forward, DLA
+loss fwd+bwd, DNN backward, [all-reduce], clip + Adagrad on both parameter groups, in-step MRR/NDCG@3,5,10
+plain + weighted).  Rank 0 prints ONE JSON line (contract in the task statement) including
+
+  roofline     -- the dominant kernel's algorithmic FLOP/s against the dense fp32-MFMA peak, its duration
+                  measured with HIP events on the launch stream (ultr_profile_*), over K more steps of the
+                  same workload right after the timed region (event pairs would perturb the timed region);
+  cpu_baseline -- the op-for-op torch-CPU restatement of the reference graph + the reference's interpreted
+                  feed loop (oracle/, kind "port"), on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from tests.util import GOLDEN, SyntheticData  # noqa: E402
+
+CONFIGS = {
+    # name: (features, list size, queries, hidden, algorithm, click model json)
+    'mslr10k': dict(F=136, L=10, Q=6000, algo='DLA', click='pbm_0.1_1.0_4_1.0.json'),
+    'yahoo': dict(F=700, L=10, Q=20000, algo='RegressionEM', click='pbm_0.1_1.0_4_1.0.json'),
+    'istella': dict(F=220, L=10, Q=20000, algo='PairDebias', click='cascade_0.1_1.0_4_1.0.json'),
+    'mslr30k': dict(F=136, L=10, Q=19000, algo='DLA', click='pbm_0.1_1.0_4_1.0.json'),
+}
+HIDDEN = [512, 256, 128]
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def train_flops_per_list(F, L):
+    """L * (6 P_W - 2 F H0): fwd + wgrad for every layer, dgrad for all but layer 0."""
+    pw = F * 512 + 512 * 256 + 256 * 128 + 128
+    return L * (6 * pw - 2 * F * 512)
+
+
+def kernel_flops_per_launch(name, F, M):
+    dims = [(F, 512), (512, 256), (256, 128)]
+    if name in ('fwd_layer_kernel', 'wgrad_kernel'):
+        return 2.0 * M * sum(k * n for k, n in dims) / 3.0, 3
+    if name == 'dgrad_kernel':
+        return 2.0 * M * sum(k * n for k, n in dims[1:]) / 2.0, 2
+    return None, 0
+
+
+def build_world(cfg, args, device):
+    from ultra_amd.utils import find_class, metrics
+    metrics.RankingMetricKey.MAX_LABEL = 4.0
+    data = SyntheticData(cfg['Q'], cfg['L'], cfg['F'], seed=1234, pad_frac=0.1)
+    exp = {'ranking_model': 'ultra_amd.ranking_model.DNN',
+           'ranking_model_hparams': 'hidden_layer_sizes=[512, 256, 128]',
+           'learning_algorithm': 'ultra_amd.learning_algorithm.' + cfg['algo'],
+           'learning_algorithm_hparams': args.algo_hparams,
+           'metrics': ['mrr', 'ndcg'], 'metrics_topn': [3, 5, 10],
+           'max_candidate_num': cfg['L'], 'selection_bias_cutoff': cfg['L'], 'seed': 1}
+    if cfg['algo'] == 'IPWrank':
+        exp['learning_algorithm_hparams'] = 'propensity_estimator_json=%s' % os.path.join(
+            GOLDEN, 'randomized_pbm_0.1_1.0_4_1.0.json')
+    model = find_class(exp['learning_algorithm'])(data, exp, False)
+    feed = find_class('ultra_amd.input_layer.ClickSimulationFeed')(
+        model, args.batch, 'click_model_json=%s,seed=2024' % os.path.join(GOLDEN, cfg['click']), None)
+    return data, exp, model, feed
+
+
+def cpu_baseline(cfg, args, data, model):
+    """The reference's path restated on the CPU: interpreted feed loop (click_simulation_feed.py:107-162) +
+    the TF graph op for op in torch fp32 (oracle/torch_graph.py).  Bounded sample."""
+    import random
+    from oracle import torch_graph as TG
+    from oracle import ultr_oracle as O
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    g = json.load(open(os.path.join(GOLDEN, cfg['click'])))
+    kind = {'DLA': 'dla', 'IPWrank': 'ipw', 'RegressionEM': 'rem', 'PairDebias': 'pd'}[cfg['algo']]
+    ps = model.model.unflatten(model.model.params)
+    kw = {}
+    if kind == 'dla':
+        pp = model.prop_params.cpu().numpy()
+        kw = dict(prop_W=pp[:cfg['L'], None], prop_b=pp[cfg['L']:])
+    ref = TG.TorchReferenceStep(kind, ps, cfg['L'], {}, dtype=torch.float32, max_label=4.0, **kw)
+    features = [list(map(float, row)) for row in data.features]  # list of lists, like Raw_data.features
+    il, labels = data.initial_list.tolist(), data.labels.tolist()
+    L, B = cfg['L'], args.batch
+    ipw = json.load(open(os.path.join(GOLDEN, 'randomized_pbm_0.1_1.0_4_1.0.json')))['IPW_list']
+    random.seed(1)
+
+    def one_step():
+        docid_inputs, letor, clicks = [], [], []
+        while len(docid_inputs) < B:  # click_simulation_feed.py:131-137
+            i = int(random.random() * len(il))
+            label_list = [0 if il[i][x] < 0 else labels[i][x] for x in range(L)]
+            c = O.sample_clicks_one_list(g['model_name'], g['click_prob'], g['exam_prob'], label_list,
+                                         [random.random() for _ in range(L)])
+            if sum(c) == 0:
+                continue
+            base = len(letor)
+            for x in range(L):
+                if il[i][x] >= 0:
+                    letor.append(features[il[i][x]])
+            docid_inputs.append([-1 if il[i][x] < 0 else base + x for x in range(L)])
+            clicks.append(c)
+        n = len(letor)
+        table = torch.from_numpy(np.array(letor).astype(np.float32))  # float64 ndarray, cast on feed (q1)
+        d = [torch.tensor([n if docid_inputs[b][l] < 0 else docid_inputs[b][l] for b in range(B)]) for l in range(L)]
+        c = [torch.tensor([float(clicks[b][l]) for b in range(B)]) for l in range(L)]
+        pw = None
+        if kind == 'ipw':
+            pw = [torch.tensor([O.propensity_for_one_list(ipw, clicks[b])[l] for b in range(B)]) for l in range(L)]
+        ref.step(table, d, c, pw_lists=pw)
+    one_step()  # warm-up
+    t0, n = time.time(), 0
+    while n < 3 or time.time() - t0 < args.cpu_seconds:
+        one_step()
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(n * B / dt, 1), 'unit': 'query-lists/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d steps of batch %d (%.1f s): python feed loop + torch-CPU fp32 graph of the reference' % (n, B, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', default='mslr10k', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=256, help='query lists per step per GPU')
+    ap.add_argument('--graph', type=int, default=-1, help='replay the step as one hipGraph (default: on for 1 GPU)')
+    ap.add_argument('--algo_hparams', default='')
+    ap.add_argument('--cpu_seconds', type=float, default=12.0)
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_profile', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=device)
+    cfg = CONFIGS[args.config]
+    data, exp, model, feed = build_world(cfg, args, device)
+    use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 0)
+
+    def step():
+        input_feed, _ = feed.get_batch(data, check_validation=True)
+        return model.step(None, input_feed, False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(max(args.warmup, 3)):
+        last = step()
+    barrier()
+    graph = None
+    if use_graph:
+        try:
+            model.enable_graph_replay(True)
+            step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                last = step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 - report and time the eager launch path instead
+            log('hipGraph capture failed (%s: %s); timing eager launches' % (type(e).__name__, e))
+            graph = None
+            model.enable_graph_replay(False)
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if graph is None:
+        last = r
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_value = float(last[0])
+    lists = args.steps * args.batch * world
+    value = lists / dt
+
+    # ---- per-kernel durations with HIP events on the launch stream (same workload, eager launches)
+    roofline, kernels = None, {}
+    if not args.no_profile:
+        from ultra_amd import _lib
+        lib = _lib.lib()
+        model.enable_graph_replay(False)
+        lib.ultr_profile_enable(1)
+        nprof = min(args.steps, 50)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.ultr_profile_report(buf, len(buf))
+        lib.ultr_profile_enable(0)
+        for line in buf.value.decode().strip().split('\n'):
+            name, cnt, ms = line.split()
+            kernels[name] = (int(cnt), float(ms))
+        M = args.batch * cfg['L']
+        best = None
+        tot_ms = sum(ms for _, ms in kernels.values())
+        for name, (cnt, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
+            fl, _ = kernel_flops_per_launch(name, cfg['F'], M)
+            log('  %-28s %6d launches  %9.3f us/launch  %8.3f us/step  %5.1f%%%s' % (
+                name, cnt, 1e3 * ms / cnt, 1e3 * ms / nprof, 100 * ms / tot_ms,
+                '' if fl is None else '  %.1f TFLOP/s' % (fl / (ms / cnt * 1e-3) / 1e12)))
+            if fl is not None and best is None:
+                best = (name, fl, ms / cnt)
+        log('  sum of kernel time per step: %.1f us' % (1e3 * tot_ms / nprof))
+        if best:
+            name, fl, ms = best
+            achieved = fl / (ms * 1e-3) / 1e12
+            roofline = {'kernel': name, 'bound': 'mfma', 'achieved': round(achieved, 3),
+                        'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                        'launch_us': round(1e3 * ms, 3), 'flops_per_launch': fl}
+
+    out = {
+        'metric': 'train query-lists/sec (DNN+DLA, MSLR-10K shape)' if args.config == 'mslr10k'
+        else 'train query-lists/sec (%s)' % args.config,
+        'value': round(value, 1), 'unit': 'query-lists/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 5), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s shape: %d features, list %d, batch %d lists/GPU, DNN[512,256,128] + %s, %s clicks, '
+                               '%d synthetic queries resident in HBM' % (
+                                   args.config, cfg['F'], cfg['L'], args.batch, cfg['algo'],
+                                   'PBM' if 'pbm' in cfg['click'] else 'cascade', cfg['Q']),
+                   'global_batch': args.batch * world, 'list_size': cfg['L'], 'parallelism': 'dp%d' % world,
+                   'launch': 'hipGraph replay' if graph is not None else 'eager',
+                   'train_gflop_per_step_per_gpu': round(train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9, 3)},
+        'final_loss': loss_value,
+    }
+    if roofline:
+        out['roofline'] = roofline
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, args, data, model)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -73,6 +73,12 @@ typedef struct UltrDnnDesc {
 int ultr_version(void);
 const char* ultr_last_error(void);
 
+/* Opt-in per-kernel timing for bench.py's roofline line (no reference counterpart): when on, every
+ * launch is bracketed by HIP events on its own stream.  ultr_profile_report synchronises and writes
+ * "kernel_name count total_ms" lines into buf (host); returns the bytes written. */
+int ultr_profile_enable(int on);
+int ultr_profile_report(char* buf_h, int buflen);
+
 /* ---- data set preparation -------------------------------------------------------------
  * Per-row LayerNorm statistics of the feature table: stats[r] = (mean, 1/sqrt(var+eps)) over
  * the F features of row r, for r < n_rows; stats[n_rows] = those of the zero pad row.

@@ -1,0 +1,529 @@
+"""GPU parity tests (-m gpu): every HIP kernel, called through the C ABI, against the CPU oracle.
+
+Bars (north_star): clicks, accepted lists, sorted permutations bit-exact under the same uniform draws;
+losses / gradients / propensities within 1e-5 relative in fp32 (tensor-wise L2-relative error: the
+oracle is float64, the kernels are exact fp32 -- fmaf-chain MFMA -- so the bound is fp32 rounding).
+"""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ultr_oracle as O
+from tests.util import load_json, SyntheticData, relerr
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # the fp32 parity bound of BASELINE.json's north_star
+
+
+@pytest.fixture(scope='module')
+def L():
+    from ultra_amd import _lib
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return _lib
+
+
+_KEEP = []  # device tensors handed to the C ABI as raw pointers must outlive the (asynchronous) launch
+
+
+@pytest.fixture(autouse=True)
+def _release_after_test():
+    yield
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def keep(t):
+    _KEEP.append(t)
+    return t
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return keep(t.cuda())
+
+
+def stream(L):
+    return L.current_stream()
+
+
+# ------------------------------------------------------------------------------------------------
+# click kernels
+# ------------------------------------------------------------------------------------------------
+def test_click_kernels_bit_exact_on_reference_goldens(L):
+    g = load_json('click_goldens.json')
+    for model in g['models']:
+        fn = L.lib().ultr_click_cascade if model['model_name'] == 'cascade_model' else L.lib().ultr_click_pbm
+        exam, cp = dev(model['exam_prob'], torch.float64), dev(model['click_prob'], torch.float64)
+        for case in model['cases']:
+            n = len(case['labels'])
+            lab, u = dev([case['labels']], torch.float32), dev([case['uniforms']], torch.float64)
+            out = torch.empty((1, n), dtype=torch.float32, device='cuda')
+            L.check(fn(L.ptr(lab), 1, n, L.ptr(exam), exam.numel(), L.ptr(cp), cp.numel(), L.ptr(u), 0, 0, L.ptr(out),
+                       stream(L)), 'click')
+            assert out.cpu().numpy()[0].tolist() == case['clicks'], (model['name'], case['seed'])
+
+
+@pytest.mark.parametrize('cascade', [False, True])
+def test_click_kernels_bulk_and_philox(L, cascade):
+    g = load_json('cascade_0.1_1.0_4_1.0.json' if cascade else 'pbm_0.1_1.0_4_1.0.json')
+    rng = np.random.RandomState(11)
+    n, Ls = 5000, 10
+    labels = rng.choice(6, size=(n, Ls)).astype(np.float32) - 0.0
+    labels[::17, 0] = -1.0
+    u = rng.random_sample((n, Ls))
+    # make some draws sit exactly ON the threshold: u < p must be false there
+    for i in range(0, n, 50):
+        u[i, 3] = g['exam_prob'][3] * g['click_prob'][min(int(max(labels[i, 3], 0)), 4)]
+    exam, cp = dev(g['exam_prob'], torch.float64), dev(g['click_prob'], torch.float64)
+    fn = L.lib().ultr_click_cascade if cascade else L.lib().ultr_click_pbm
+    out = torch.empty((n, Ls), dtype=torch.float32, device='cuda')
+    L.check(fn(L.ptr(dev(labels)), n, Ls, L.ptr(exam), 10, L.ptr(cp), 5, L.ptr(dev(u)), 0, 0, L.ptr(out), stream(L)), 'click')
+    want = np.array([O.sample_clicks_one_list(g['model_name'], g['click_prob'], g['exam_prob'], list(labels[i]), u[i])
+                     for i in range(n)], dtype=np.float32)
+    assert np.array_equal(out.cpu().numpy(), want)
+    # Philox mode: the device stream equals the oracle's restatement of it, draw for draw
+    seed, step = 0x1234567890ABCDEF, 7
+    L.check(fn(L.ptr(dev(labels)), n, Ls, L.ptr(exam), 10, L.ptr(cp), 5, None, seed, step, L.ptr(out), stream(L)), 'click')
+    got = out.cpu().numpy()
+    for i in list(range(0, 40)) + [n - 1]:
+        ui = O.philox_uniforms(seed, step, i, 0, Ls)
+        assert got[i].tolist() == [float(c) for c in O.sample_clicks_one_list(
+            g['model_name'], g['click_prob'], g['exam_prob'], list(labels[i]), ui)]
+    rate = got.mean()
+    assert 0.02 < rate < 0.6
+    # empty input is a no-op
+    assert fn(L.ptr(dev(labels)), 0, Ls, L.ptr(exam), 10, L.ptr(cp), 5, None, 0, 0, L.ptr(out), stream(L)) == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# batch assembly
+# ------------------------------------------------------------------------------------------------
+def _assemble(L, data, B, Ls, model, mode, seed=0, step=0, slot_base=0, u=None, slot_start=0, check=1,
+              step_ctr=None, out=None, max_attempts=100):
+    il, lab = dev(data.initial_list, torch.int32), dev(data.labels, torch.float32)
+    exam, cp = dev(model['exam_prob'], torch.float64), dev(model['click_prob'], torch.float64)
+    kind = {'position_biased_model': 0, 'cascade_model': 1, 'oracle': 2}[model['model_name']]
+    if out is None:
+        out = (torch.full((Ls, B), -7, dtype=torch.int32, device='cuda'),
+               torch.full((Ls, B), -7.0, dtype=torch.float32, device='cuda'),
+               torch.full((B,), -7, dtype=torch.int32, device='cuda'), torch.zeros(4, dtype=torch.int32, device='cuda'))
+    ud = None if u is None else dev(u, torch.float64)
+    n_cand = 0 if u is None else u.shape[0]
+    n_rows = data.features.shape[0]
+    L.check(L.lib().ultr_batch_assemble(
+        L.ptr(il), L.ptr(lab), il.shape[0], il.shape[1], Ls, B, kind, L.ptr(exam), exam.numel(), L.ptr(cp), cp.numel(),
+        mode, seed, step, L.ptr(step_ctr), slot_base, L.ptr(ud), n_cand, slot_start, check, max_attempts, n_rows,
+        L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), stream(L)), 'assemble')
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize('model_file', ['pbm_0.1_1.0_4_1.0.json', 'cascade_0.1_1.0_4_1.0.json'])
+def test_batch_assemble_sequential_bit_exact(L, model_file):
+    model = load_json(model_file)
+    data = SyntheticData(300, 12, 8, seed=21, pad_frac=0.3)
+    Ls, B = 10, 256
+    rng = np.random.RandomState(5)
+    n_cand = 3000  # > 1024: several rounds of the single-workgroup loop
+    u = rng.random_sample((n_cand, 1 + Ls))
+    docids, clicks, idx, info = _assemble(L, data, B, Ls, model, 1, u=u)
+    want_idx, want_clicks, want_n = O.get_batch_sequential(
+        data.initial_list, data.labels, Ls, B, model['model_name'], model['click_prob'], model['exam_prob'],
+        u.reshape(-1), True)
+    assert info.cpu().tolist()[:2] == [want_n, B]
+    assert idx.cpu().tolist() == want_idx
+    assert np.array_equal(clicks.cpu().numpy().T, np.array(want_clicks, dtype=np.float32))
+    il = data.initial_list[want_idx][:, :Ls]
+    assert np.array_equal(docids.cpu().numpy().T, np.where(il < 0, data.features.shape[0], il))
+    # shortfall: too few candidates -> partial fill, then a second call continues from slot_start
+    out = _assemble(L, data, B, Ls, model, 1, u=u[:200])
+    consumed, filled = out[3].cpu().tolist()[:2]
+    assert consumed == 200 and 0 < filled < B
+    out = _assemble(L, data, B, Ls, model, 1, u=u[200:], slot_start=filled, out=out)
+    assert out[3].cpu().tolist()[:2] == [want_n - 200, B] and out[2].cpu().tolist() == want_idx
+
+
+def test_batch_assemble_philox_slots_bit_exact_and_dp_invariant(L):
+    model = load_json('pbm_0.1_1.0_4_1.0.json')
+    data = SyntheticData(500, 10, 8, seed=22, pad_frac=0.2)
+    Ls, B, seed, step = 10, 512, 0xC0FFEE1234, 3
+    docids, clicks, idx, info = _assemble(L, data, B, Ls, model, 0, seed=seed, step=step)
+    w_idx, w_clicks, w_att = O.get_batch_slots(data.initial_list, data.labels, Ls, 64, model['model_name'],
+                                               model['click_prob'], model['exam_prob'], seed, step)
+    assert idx.cpu().tolist()[:64] == w_idx
+    assert np.array_equal(clicks.cpu().numpy().T[:64], np.array(w_clicks, dtype=np.float32))
+    assert (clicks.sum(dim=0) > 0).all()
+    assert info.cpu().tolist()[2] >= B  # total attempts
+    # two "ranks" with B/2 lists each reproduce the one-big-batch run bit for bit
+    a = _assemble(L, data, B // 2, Ls, model, 0, seed=seed, step=step, slot_base=0)
+    b = _assemble(L, data, B // 2, Ls, model, 0, seed=seed, step=step, slot_base=B // 2)
+    assert torch.equal(torch.cat([a[2], b[2]]), idx) and torch.equal(torch.cat([a[1], b[1]], dim=1), clicks)
+    # device-resident step counter: added to `step`, bumped once per call
+    ctr = torch.tensor([step], dtype=torch.int32, device='cuda')
+    c = _assemble(L, data, B, Ls, model, 0, seed=seed, step=0, step_ctr=ctr)
+    assert torch.equal(c[2], idx) and ctr.item() == step + 1
+    # oracle mode feeds the labels themselves, lists without a relevant doc in the top L are rejected
+    o = _assemble(L, data, 128, Ls, {'model_name': 'oracle', 'exam_prob': [1.0], 'click_prob': [1.0]}, 0, seed=1)
+    got_idx = o[2].cpu().numpy()
+    lab = np.where(data.initial_list[got_idx][:, :Ls] < 0, 0, data.labels[got_idx][:, :Ls])
+    assert np.array_equal(o[1].cpu().numpy().T, lab.astype(np.float32)) and (lab.sum(1) > 0).all()
+    # error behaviour: lists shorter than rank_list_size (ValueError in the reference feed)
+    il = dev(data.initial_list, torch.int32)
+    rc = L.lib().ultr_batch_assemble(L.ptr(il), L.ptr(il), 500, 10, 11, 4, 0, L.ptr(il), 1, L.ptr(il), 1, 0, 0, 0, None,
+                                     0, None, 0, 0, 1, 100, 1, L.ptr(il), L.ptr(il), L.ptr(il), L.ptr(il), None)
+    assert rc == -1 and b'no less than the required list size' in L.lib().ultr_last_error()
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+def _scores_clicks(rng, B, Ls):
+    scores = rng.normal(scale=1.5, size=(B, Ls))
+    clicks = (rng.uniform(size=(B, Ls)) < 0.25).astype(np.float64)
+    clicks[clicks.sum(1) == 0, rng.randint(0, Ls)] = 1.0
+    return scores, clicks
+
+
+def _loss_ws(L, B, Ls):
+    return keep(torch.zeros(L.lib().ultr_loss_workspace_floats(B, Ls), dtype=torch.float32, device='cuda'))
+
+
+@pytest.mark.parametrize('B,Ls', [(256, 10), (1000, 9), (3, 1), (5000, 16)])
+@pytest.mark.parametrize('loss_func,prob,maxw', [(0, 0, -1.0), (1, 0, -1.0), (0, 1, 3.0)])
+def test_dla_loss_kernel(L, B, Ls, loss_func, prob, maxw):
+    rng = np.random.RandomState(B + Ls)
+    scores, clicks = _scores_clicks(rng, B, Ls)
+    W, b = rng.uniform(-0.7, 0.7, size=(Ls, 1)), rng.uniform(-0.5, 0.5, size=(1,))
+    ref = O.dla_losses(scores, clicks, W, b, 'sigmoid_loss' if loss_func else 'softmax_loss',
+                       'sigmoid' if prob else 'softmax', maxw)
+    s, c = dev(scores.T, torch.float32), dev(clicks.T, torch.float32)
+    pp = dev(np.concatenate([W[:, 0], b]), torch.float32)
+    d = torch.empty_like(s)
+    pg = torch.empty(Ls + 1, dtype=torch.float32, device='cuda')
+    lw = torch.empty(B, dtype=torch.float32, device='cuda')
+    stats = torch.zeros(4 + 3 * Ls, dtype=torch.float32, device='cuda')
+    ws = _loss_ws(L, B, Ls)
+    for _ in range(2):  # twice: the arrival counter must be left clean
+        L.check(L.lib().ultr_loss_dla_fwdbwd(L.ptr(s), L.ptr(c), B, Ls, L.ptr(pp), loss_func, prob, maxw, L.ptr(d),
+                                             L.ptr(pg), L.ptr(lw), L.ptr(stats), L.ptr(ws), stream(L)), 'dla')
+    st = stats.cpu().numpy().astype(np.float64)
+    assert abs(st[0] / st[1] - ref['rank_loss']) <= RTOL * abs(ref['rank_loss']) + 1e-12   # L = 1: the loss is 0
+    assert abs(st[2] / st[3] - ref['exam_loss']) <= RTOL * abs(ref['exam_loss']) + 1e-12
+    assert relerr(d.cpu().numpy().T / st[1], ref['d_output']) < RTOL or Ls == 1
+    pgn = pg.cpu().numpy().astype(np.float64) / st[3]
+    assert relerr(pgn[:Ls], ref['d_prop_W'][:, 0]) < 5 * RTOL or Ls == 1   # differences of O(B) sums: a few ulps more
+    assert abs(pgn[Ls] - ref['d_prop_b'][0]) <= 5 * RTOL * np.abs(ref['d_prop_W']).sum()
+    assert relerr(st[4:4 + Ls], ref['propensity_weights'][0]) < RTOL
+    assert relerr(st[4 + Ls:4 + 2 * Ls] / B, ref['relevance_weights'].mean(0)) < RTOL
+    want_lw = (ref['propensity_weights'] * np.clip(clicks, 0, 1)).mean(1)
+    assert relerr(lw.cpu().numpy(), want_lw) < RTOL
+
+
+@pytest.mark.parametrize('B,Ls,loss_func', [(256, 10, 0), (777, 7, 0), (256, 10, 1)])
+def test_ipw_loss_kernel(L, B, Ls, loss_func):
+    rng = np.random.RandomState(3)
+    scores, clicks = _scores_clicks(rng, B, Ls)
+    ipw = load_json('randomized_pbm_0.1_1.0_4_1.0.json')['IPW_list']
+    pw_ref = np.array([O.propensity_for_one_list(ipw, list(c)) for c in clicks])
+    s, c = dev(scores.T, torch.float32), dev(clicks.T, torch.float32)
+    pw = torch.empty_like(s)
+    L.check(L.lib().ultr_ipw_weights(L.ptr(c), B, Ls, L.ptr(dev(ipw[:Ls], torch.float32)), Ls, L.ptr(pw), stream(L)), 'ipww')
+    assert np.array_equal(pw.cpu().numpy().T, pw_ref.astype(np.float32))
+    if loss_func == 0:
+        loss, d_ref, tot = O.softmax_loss(scores, clicks, pw_ref)
+    else:
+        loss, d_ref = O.sigmoid_loss_on_list(scores, clicks, pw_ref)
+        tot = B
+        d_ref = d_ref * B
+    d = torch.empty_like(s)
+    stats = torch.zeros(2 + Ls, dtype=torch.float32, device='cuda')
+    lw = torch.empty(B, dtype=torch.float32, device='cuda')
+    L.check(L.lib().ultr_loss_ipw_fwdbwd(L.ptr(s), L.ptr(c), L.ptr(pw), B, Ls, loss_func, L.ptr(d), L.ptr(stats),
+                                         L.ptr(lw), L.ptr(_loss_ws(L, B, Ls)), stream(L)), 'ipw')
+    st = stats.cpu().numpy().astype(np.float64)
+    assert abs(st[0] / st[1] - loss) < RTOL * abs(loss)
+    if loss_func == 0:
+        assert relerr(d.cpu().numpy().T / st[1], d_ref) < RTOL
+    else:
+        assert relerr(d.cpu().numpy().T, d_ref) < RTOL and st[1] == B
+    assert np.allclose(st[2:], pw_ref.max(0), rtol=1e-6)
+    assert relerr(lw.cpu().numpy(), (pw_ref * np.clip(clicks, 0, 1)).mean(1)) < RTOL
+
+
+@pytest.mark.parametrize('B,Ls', [(256, 10), (1500, 6)])
+def test_rem_loss_kernel(L, B, Ls):
+    rng = np.random.RandomState(9)
+    scores, clicks = _scores_clicks(rng, B, Ls)
+    p = rng.uniform(0.2, 0.95, size=(1, Ls))
+    bias = 0.3
+    u = rng.uniform(size=(B, Ls)).astype(np.float32)
+    loss, d_ref, new_p, y_ref = O.rem_step(scores.astype(np.float32).astype(np.float64) + np.float32(bias), clicks, p,
+                                           0.05, u.astype(np.float64))
+    s, c = dev(scores.T, torch.float32), dev(clicks.T, torch.float32)
+    prop = dev(p[0], torch.float32)
+    d, y = torch.empty_like(s), torch.empty_like(s)
+    lw = torch.empty(B, dtype=torch.float32, device='cuda')
+    stats = torch.zeros(3 + 3 * Ls, dtype=torch.float32, device='cuda')
+    db = torch.zeros(1, dtype=torch.float32, device='cuda')
+    L.check(L.lib().ultr_loss_rem_fwdbwd(L.ptr(s), L.ptr(c), B, Ls, L.ptr(prop), L.ptr(dev([bias], torch.float32)),
+                                         L.ptr(dev(u.T)), 0, 0, None, 0, L.ptr(d), L.ptr(y), L.ptr(lw), L.ptr(stats),
+                                         L.ptr(db), L.ptr(_loss_ws(L, B, Ls)), stream(L)), 'rem')
+    st = stats.cpu().numpy().astype(np.float64)
+    yk = y.cpu().numpy().T
+    # a Bernoulli label can only differ where p_r1 - u is within fp32 rounding of 0
+    assert (yk != y_ref).mean() < 1e-3
+    same = (yk == y_ref).all(axis=1)
+    assert relerr((d.cpu().numpy().T / B)[same], d_ref[same]) < RTOL
+    assert st[1] == B and abs(db.item() - d.sum().item()) < 1e-3 * B
+    old = torch.empty(Ls, dtype=torch.float32, device='cuda')
+    L.check(L.lib().ultr_rem_update_propensity(L.ptr(prop), Ls, L.ptr(stats), 0.05, L.ptr(old), stream(L)), 'remup')
+    assert relerr(prop.cpu().numpy(), new_p[0]) < RTOL and relerr(old.cpu().numpy(), p[0]) < 1e-7
+    assert relerr(st[2 + Ls:2 + 2 * Ls], yk.sum(0)) < 1e-6 and relerr(st[2 + 2 * Ls:2 + 3 * Ls], clicks.sum(0)) < 1e-6
+    assert relerr(lw.cpu().numpy(), (np.clip(clicks, 0, 1) / p).mean(1)) < RTOL
+    # Philox-drawn labels: right marginal frequency, different across steps
+    L.check(L.lib().ultr_loss_rem_fwdbwd(L.ptr(s), L.ptr(c), B, Ls, L.ptr(dev(p[0], torch.float32)), None, None, 5, 1,
+                                         None, 0, L.ptr(d), L.ptr(y), None, L.ptr(stats), None,
+                                         L.ptr(_loss_ws(L, B, Ls)), stream(L)), 'rem')
+    y1 = y.clone()
+    L.check(L.lib().ultr_loss_rem_fwdbwd(L.ptr(s), L.ptr(c), B, Ls, L.ptr(dev(p[0], torch.float32)), None, None, 5, 2,
+                                         None, 0, L.ptr(d), L.ptr(y), None, L.ptr(stats), None,
+                                         L.ptr(_loss_ws(L, B, Ls)), stream(L)), 'rem')
+    assert not torch.equal(y1, y) and ((y1 == 0) | (y1 == 1)).all() and (y1 >= c).all()
+
+
+@pytest.mark.parametrize('B,Ls', [(256, 10), (900, 5), (64, 32)])
+def test_pd_loss_kernel(L, B, Ls):
+    rng = np.random.RandomState(13)
+    scores, clicks = _scores_clicks(rng, B, Ls)
+    tp, tm = rng.uniform(0.5, 1.5, size=(1, Ls)), rng.uniform(0.5, 1.5, size=(1, Ls))
+    loss, d_ref, ntp, ntm, pair = O.pd_step(scores, clicks, tp, tm, 0.05, 1)
+    s, c = dev(scores.T, torch.float32), dev(clicks.T, torch.float32)
+    tpd, tmd = dev(tp[0], torch.float32), dev(tm[0], torch.float32)
+    d = torch.empty_like(s)
+    stats = torch.zeros(Ls * Ls + 1, dtype=torch.float32, device='cuda')
+    L.check(L.lib().ultr_loss_pd_fwdbwd(L.ptr(s), L.ptr(c), B, Ls, L.ptr(tpd), L.ptr(tmd), L.ptr(d), L.ptr(stats),
+                                        L.ptr(_loss_ws(L, B, Ls)), stream(L)), 'pd')
+    st = stats.cpu().numpy().astype(np.float64)
+    assert relerr(st[:Ls * Ls].reshape(Ls, Ls), pair) < RTOL
+    assert abs(st[Ls * Ls] - loss[0, 0]) < RTOL * abs(loss[0, 0])
+    assert relerr(d.cpu().numpy().T, d_ref) < RTOL
+    old = torch.empty(2 * Ls, dtype=torch.float32, device='cuda')
+    L.check(L.lib().ultr_pd_update_ratios(L.ptr(tpd), L.ptr(tmd), Ls, L.ptr(stats), 0.05, 1.0, L.ptr(old), stream(L)), 'pdup')
+    assert relerr(tpd.cpu().numpy(), ntp[0]) < RTOL and relerr(tmd.cpu().numpy(), ntm[0]) < RTOL
+    assert abs(stats[Ls * Ls].item() - loss[0, 0]) < RTOL * abs(loss[0, 0])
+
+
+def test_pd_no_pair_at_position0_gives_nan_like_reference(L):
+    # q17: ratios divide by position-0 sums; no clicked-over-unclicked pair at rank 0 -> 0/0
+    B, Ls = 8, 4
+    scores = np.zeros((B, Ls))
+    clicks = np.zeros((B, Ls))
+    clicks[:, 2] = 1.0
+    tpd, tmd = torch.ones(Ls, device='cuda'), torch.ones(Ls, device='cuda')
+    stats = torch.zeros(Ls * Ls + 1, device='cuda')
+    d = torch.empty((Ls, B), device='cuda')
+    L.check(L.lib().ultr_loss_pd_fwdbwd(L.ptr(dev(scores.T, torch.float32)), L.ptr(dev(clicks.T, torch.float32)), B, Ls,
+                                        L.ptr(tpd), L.ptr(tmd), L.ptr(d), L.ptr(stats), L.ptr(_loss_ws(L, B, Ls)),
+                                        stream(L)), 'pd')
+    L.check(L.lib().ultr_pd_update_ratios(L.ptr(tpd), L.ptr(tmd), Ls, L.ptr(stats), 0.05, 1.0, None, stream(L)), 'pdup')
+    with np.errstate(all='ignore'):
+        _, _, ntp, ntm, _ = O.pd_step(scores, clicks, np.ones((1, Ls)), np.ones((1, Ls)), 0.05, 1)
+    assert np.array_equal(np.isnan(tpd.cpu().numpy()), np.isnan(ntp[0]))
+    assert np.array_equal(np.isinf(tpd.cpu().numpy()), np.isinf(ntp[0]))
+
+
+# ------------------------------------------------------------------------------------------------
+# metrics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,Lx', [(256, 10), (37, 9), (20, 1), (50, 33), (9, 120), (5, 700)])
+def test_sort_permutation_bit_exact_with_ties(L, B, Lx):
+    from ultra_amd.utils.metrics import sort_by_scores_indices
+    rng = np.random.RandomState(Lx)
+    scores = np.round(rng.normal(size=(B, Lx)), 1).astype(np.float32)  # many exact ties
+    scores[0, :] = 0.0
+    u = rng.uniform(size=(B, Lx)).astype(np.float32)
+    u[1, :] = 0.5                                                     # ties in the shuffle too -> index order
+    for topn in (None, 3):
+        got = sort_by_scores_indices(dev(scores), dev(u), topn).cpu().numpy()
+        assert np.array_equal(got, O.sort_permutation(scores, u, topn))
+    got = sort_by_scores_indices(dev(scores), None, None).cpu().numpy()
+    assert np.array_equal(got, O.sort_permutation(scores, None, None))
+
+
+@pytest.mark.parametrize('B,Lx', [(256, 10), (100, 9), (33, 40), (6, 300)])
+def test_metrics_kernel(L, B, Lx):
+    from ultra_amd.utils import metrics as M
+    rng = np.random.RandomState(B)
+    labels = rng.choice(3, size=(B, Lx), p=[0.7, 0.2, 0.1]).astype(np.float64)
+    labels[3 % B] = 0.0                                   # a list without any relevant doc
+    scores = np.round(rng.normal(size=(B, Lx)), 2)
+    n_rows = 1000
+    docids = rng.randint(0, n_rows, size=(B, Lx))
+    docids[:, Lx - 1] = np.where(rng.uniform(size=B) < 0.5, n_rows, docids[:, Lx - 1])  # some pads
+    labels[docids == n_rows] = 0.0
+    u = rng.uniform(size=(B, Lx)).astype(np.float32)
+    w = rng.uniform(0.0, 2.0, size=(B, 1))
+    w[5 % B] = 0.0
+    topn = [1, 3, 5, 10]
+    plan = M.MetricPlan(['mrr', 'ndcg', 'err'], topn)
+    out = torch.zeros(plan.n_out, dtype=torch.float32, device='cuda')
+    ws = M.metrics_workspace(B, plan, 'cuda')
+    s32 = scores.astype(np.float32)
+    for _ in range(2):
+        M.batch_metrics(plan, dev(s32.T), dev(labels.T, torch.float32), dev(docids.T, torch.int32), n_rows,
+                        dev(w[:, 0], torch.float32), out, ws, dev(u), max_label=2.0)
+    got = out.cpu().numpy().astype(np.float64)
+    masked = O.remove_padding(s32.astype(np.float64), docids, n_rows)
+    for i, k in enumerate(topn):
+        for weighted, ww in ((False, None), (True, w)):
+            assert abs(got[plan.slot('ndcg', i, weighted)] - O.ndcg(labels, masked, ww, k, u, u)) < 2e-6
+            assert abs(got[plan.slot('err', i, weighted)] - O.err(labels, masked, 2.0, ww, k, u)) < 2e-6
+            assert abs(got[plan.slot('mrr', i, weighted)] - O.mrr(labels, masked, ww, u)) < 2e-6
+    # invalid (negative) labels are reset and pushed to the end (metrics.py:241-250)
+    labels2 = labels.copy()
+    labels2[:, 0] = -1.0
+    plan2 = M.MetricPlan(['ndcg'], [5])
+    out2 = torch.zeros(plan2.n_out, dtype=torch.float32, device='cuda')
+    M.batch_metrics(plan2, dev(s32.T), dev(labels2.T, torch.float32), None, 0, None, out2, keep(M.metrics_workspace(B, plan2, 'cuda')),
+                    dev(u), max_label=2.0)
+    assert abs(out2[0].item() - O.ndcg(labels2, s32.astype(np.float64), None, 5, u, u)) < 2e-6
+    # the factory API of the reference (metrics.py:64)
+    fn = M.make_ranking_metric_fn('ndcg', 3)
+    v = fn(dev(labels, torch.float32), dev(s32), None)
+    assert abs(v.item() - O.ndcg(labels, s32.astype(np.float64), None, 3)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,strategy,clip,l2', [(236608, 0, 5.0, 0.0), (236611, 0, 0.5, 1e-3), (11, 0, 5.0, 0.0),
+                                                (5000, 1, 0.0, 0.0), (1 << 21, 0, 1.0, 0.0)])
+def test_clip_adagrad(L, n, strategy, clip, l2):
+    rng = np.random.RandomState(n % 1000)
+    theta, acc = rng.normal(size=n), rng.uniform(0.1, 1.0, size=n)
+    g = rng.normal(scale=0.01, size=n)
+    denom = 7.5
+    th, ac, gr = dev(theta, torch.float32), dev(acc, torch.float32), dev(g, torch.float32)
+    dn = dev([denom], torch.float32)
+    nrm = torch.zeros(1, device='cuda')
+    ws = torch.zeros(2048, device='cuda')
+    L.check(L.lib().ultr_clip_adagrad(L.ptr(th), L.ptr(ac) if strategy == 0 else None, L.ptr(gr), n, L.ptr(dn), 2.0,
+                                      l2, clip, 0.05, strategy, L.ptr(nrm), L.ptr(ws), stream(L)), 'opt')
+    t32, a32, g32 = theta.astype(np.float32).astype(np.float64), acc.astype(np.float32).astype(np.float64), \
+        g.astype(np.float32).astype(np.float64)
+    gg = g32 * 2.0 / denom + l2 * t32
+    want_norm = np.sqrt((gg ** 2).sum())
+    if clip > 0:
+        gg = gg * clip / max(want_norm, clip)
+    if strategy == 0:
+        want_t, want_a = O.adagrad_update(t32, a32, gg, 0.05)
+        assert relerr(ac.cpu().numpy(), want_a) < 1e-6
+    else:
+        want_t = O.sgd_update(t32, gg, 0.05)
+    assert abs(nrm.item() - want_norm) < RTOL * want_norm
+    assert relerr(th.cpu().numpy(), want_t) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# DNN forward / backward
+# ------------------------------------------------------------------------------------------------
+def _dnn_case(L, F, hidden, act, norm, B, Ls, seed, pad_frac=0.2):
+    from ultra_amd.ranking_model import DNN
+    from ultra_amd.ranking_model.DNN import feature_row_stats
+    rng = np.random.RandomState(seed)
+    data = SyntheticData(max(B // 2, 4), Ls, F, seed=seed, pad_frac=pad_frac, sparse=0.5)
+    n_rows = data.features.shape[0]
+    lists = rng.randint(0, data.initial_list.shape[0], size=B)
+    docids = np.where(data.initial_list[lists] < 0, n_rows, data.initial_list[lists]).astype(np.int32)  # [B, Ls]
+    hs = 'hidden_layer_sizes=[%s],activation_func=%s,norm=%s' % (', '.join(map(str, hidden)), act, norm) if hidden \
+        else 'activation_func=%s,norm=%s' % (act, norm)
+    model = DNN(hs)
+    if not hidden:
+        model.hparams.hidden_layer_sizes = []
+    model.create_variables(F, 'cuda', seed=seed)
+    ps = O.init_dnn_params(rng, F, hidden, dtype=np.float32)
+    for p in ps:
+        p['gamma'] = rng.uniform(0.5, 1.5, size=p['gamma'].shape).astype(np.float32)
+        p['beta'] = rng.uniform(-0.3, 0.3, size=p['beta'].shape).astype(np.float32)
+    model.load_numpy_params(ps)
+    ldx = (F + 3) // 4 * 4
+    table = torch.zeros((n_rows, ldx), dtype=torch.float32, device='cuda')
+    table[:, :F] = dev(data.features)
+    stats = feature_row_stats(table, F) if norm == 'layer' else None
+    d_lb = dev(docids.T)
+    return model, ps, data, table, stats, n_rows, docids, d_lb, rng
+
+
+DNN_CASES = [
+    (136, [512, 256, 128], 'elu', 'layer', 256, 10),   # BASELINE config 2 (MSLR-10K shape)
+    (136, [512, 256, 128], 'elu', 'layer', 100, 9),    # toy-like: L = 9, ragged M
+    (700, [512, 256, 128], 'elu', 'layer', 64, 10),    # Yahoo shape
+    (220, [512, 256, 128], 'elu', 'layer', 64, 10),    # Istella-S shape
+    (46, [64, 32], 'relu', 'none', 50, 7),             # no normalisation
+    (10, [100, 30], 'tanh', 'layer', 33, 5),           # widths that are not multiples of 32
+    (21, [50], 'selu', 'layer', 40, 3),                # F not a multiple of 4
+    (30, [20, 20, 20, 20], 'sigmoid', 'layer', 17, 4), # deeper, tiny
+    (136, [], 'elu', 'layer', 40, 10),                 # Linear-like: no hidden layer
+    (64, [1024], 'elu', 'layer', 40, 3),               # maximum width
+]
+
+
+@pytest.mark.parametrize('F,hidden,act,norm,B,Ls', DNN_CASES)
+def test_dnn_forward_backward(L, F, hidden, act, norm, B, Ls):
+    model, ps, data, table, stats, n_rows, docids, d_lb, rng = _dnn_case(L, F, hidden, act, norm, B, Ls, seed=F + B)
+    scores = model.forward_lists(table, stats, n_rows, d_lb)
+    ps64 = [{k: v.astype(np.float64) for k, v in p.items()} for p in ps]
+    x = O.gather_rows(data.features.astype(np.float64), docids.T.reshape(-1))
+    ref, cache = O.dnn_forward(ps64, x, act, norm)
+    got = scores.cpu().numpy().reshape(-1)
+    assert relerr(got, ref[:, 0]) < RTOL
+    # pad rows (doc id == n_rows) score like the zero feature row
+    d_out = rng.normal(size=(Ls * B)).astype(np.float32)
+    grads = torch.full((model.n_total,), 7.0, dtype=torch.float32, device='cuda')
+    model.backward(dev(d_out).view(Ls, B), grads)
+    g_ref = O.dnn_backward(ps64, cache, d_out.astype(np.float64)[:, None], act, norm)
+    g_got = model.unflatten(grads)
+    total = np.sqrt(sum((g_ref[j][k] ** 2).sum() for j in range(len(ps)) for k in g_ref[j]))
+    for j in range(len(ps)):
+        for k in ('W', 'b') + (('gamma', 'beta') if norm == 'layer' else ()):
+            err = np.linalg.norm(g_got[j][k].reshape(g_ref[j][k].shape) - g_ref[j][k])
+            assert err < RTOL * max(np.linalg.norm(g_ref[j][k]), 1e-3 * total), (j, k, err)
+    # padding of the flat buffer stays exactly zero, the spare tail is untouched
+    flat = grads.cpu().numpy()
+    used = np.zeros(model.n_total, bool)
+    for ent in model.slices:
+        o, ln = ent['W']
+        w = np.zeros((ent['K'], ent['ldw']), bool)
+        w[:, :ent['N']] = True
+        used[o:o + ln] = w.reshape(-1)
+        for nm in ('b', 'gamma', 'beta'):
+            o, ln = ent[nm]
+            used[o:o + ln] = True
+    assert (flat[:model.desc.n_params][~used[:model.desc.n_params]] == 0).all()
+    assert (flat[model.desc.n_params:] == 7.0).all()
+
+
+def test_dnn_build_reference_api(L):
+    from ultra_amd.ranking_model import DNN
+    rng = np.random.RandomState(0)
+    B, Ls, F = 32, 4, 24
+    model = DNN('hidden_layer_sizes=[32, 16]')
+    xs = [rng.uniform(-1, 1, size=(B, F)).astype(np.float32) for _ in range(Ls)]
+    outs = model.build([dev(x) for x in xs], is_training=True)
+    assert len(outs) == Ls and tuple(outs[0].shape) == (B, 1)
+    ps = [{k: v.astype(np.float64) for k, v in p.items()} for p in model.unflatten(model.params)]
+    ref, _ = O.dnn_forward(ps, np.concatenate(xs, 0).astype(np.float64))
+    assert relerr(torch.cat(outs, 0).cpu().numpy(), ref) < RTOL
+    assert 'ranking_model/dnn_W_0:0' in model.model_parameters
+    # biases are Glorot-uniform, not zero (tf.get_variable default initializer)
+    b0 = model.model_parameters['ranking_model/dnn_b_0:0'].cpu().numpy()[:32]
+    assert np.abs(b0).max() > 0 and np.abs(b0).max() <= np.sqrt(6.0 / 64) + 1e-6
+    with pytest.raises(NotImplementedError):
+        DNN('norm=batch').create_variables(8, 'cuda')

@@ -1,0 +1,285 @@
+"""GPU parity tests (-m gpu) of the whole training step behind the plugin API: ClickSimulationFeed.get_batch
+-> Algorithm.step, against the op-for-op torch-CPU restatement of the reference graphs (oracle/torch_graph.py,
+float64) on the SAME sampled batches and the same initial variables.  Tolerance: 1e-5 relative (fp32), with
+the accumulation over steps stated where it applies."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_graph as TG
+from oracle import ultr_oracle as O
+from tests.util import GOLDEN, SyntheticData, relerr, relerr_floor
+
+pytestmark = pytest.mark.gpu
+
+PBM = os.path.join(GOLDEN, 'pbm_0.1_1.0_4_1.0.json')
+CASCADE = os.path.join(GOLDEN, 'cascade_0.1_1.0_4_1.0.json')
+IPW_JSON = os.path.join(GOLDEN, 'randomized_pbm_0.1_1.0_4_1.0.json')
+
+
+def settings(algo, algo_hparams='', model_hparams='hidden_layer_sizes=[64, 32]', Lmax=10, cutoff=10, feed_hparams=None):
+    return {
+        'train_input_feed': 'ultra_amd.input_layer.ClickSimulationFeed',
+        'train_input_hparams': feed_hparams if feed_hparams is not None else 'click_model_json=%s' % PBM,
+        'valid_input_feed': 'ultra_amd.input_layer.DirectLabelFeed', 'valid_input_hparams': '',
+        'ranking_model': 'ultra_amd.ranking_model.DNN', 'ranking_model_hparams': model_hparams,
+        'learning_algorithm': 'ultra_amd.learning_algorithm.' + algo, 'learning_algorithm_hparams': algo_hparams,
+        'metrics': ['mrr', 'ndcg'], 'metrics_topn': [3, 5, 10], 'objective_metric': 'ndcg_10',
+        'max_candidate_num': Lmax, 'selection_bias_cutoff': cutoff, 'seed': 1,
+    }
+
+
+def make(algo, data, exp, B):
+    from ultra_amd.utils import find_class, metrics
+    metrics.RankingMetricKey.MAX_LABEL = 4.0
+    model = find_class(exp['learning_algorithm'])(data, exp, False)
+    feed = find_class(exp['train_input_feed'])(model, B, exp['train_input_hparams'], None)
+    return model, feed
+
+
+def tie_uniforms(model, rng, B, L=10):
+    """Clicked PAD documents tie at PADDING_SCORE; the reference breaks ties with fresh uniforms
+    (metric_utils.py:76-81), so both sides get the same ones."""
+    u = rng.uniform(size=(B, L)).astype(np.float32)
+    model.metric_uniforms = torch.tensor(u).cuda()
+    return torch.tensor(u)
+
+
+def torch_feed(data, batch):
+    docids = batch.docids.cpu().numpy()
+    clicks = batch.labels.cpu().numpy()
+    table = torch.tensor(data.features.astype(np.float64))
+    d = [torch.tensor(docids[l].astype(np.int64)) for l in range(docids.shape[0])]
+    c = [torch.tensor(clicks[l].astype(np.float64)) for l in range(docids.shape[0])]
+    return table, d, c
+
+
+def reference_for(kind, model, L, hparams, **kw):
+    ps = [{k: v.astype(np.float64) for k, v in p.items()} for p in model.model.unflatten(model.model.params)]
+    return TG.TorchReferenceStep(kind, ps, L, hparams, max_label=4.0, **kw)
+
+
+def compare_params(model, ref, tol):
+    got = model.model.unflatten(model.model.params)
+    for j, p in enumerate(ref.params):
+        for k in ('W', 'b', 'gamma', 'beta'):
+            assert relerr_floor(got[j][k].reshape(p[k].shape), p[k].detach().numpy(), 1e-3) < tol, (j, k)
+
+
+@pytest.mark.parametrize('hp,B', [('', 256), ('loss_func=sigmoid_loss,l2_loss=0.001', 96),
+                                  ('logits_to_prob=sigmoid,max_propensity_weight=4,ranker_loss_weight=2.0', 96),
+                                  ('grad_strategy=sgd,learning_rate=0.01,max_gradient_norm=0.0', 64)])
+def test_dla_steps_match_reference_graph(hp, B):
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(400, 10, 24, seed=3, pad_frac=0.2)
+    exp = settings('DLA', hp)
+    model, feed = make('DLA', data, exp, B)
+    hpd = {k: getattr(model.hparams, k) for k in ('learning_rate', 'max_gradient_norm', 'loss_func', 'logits_to_prob',
+                                                   'propensity_learning_rate', 'ranker_loss_weight', 'l2_loss',
+                                                   'max_propensity_weight', 'grad_strategy')}
+    pp = model.prop_params.cpu().numpy().astype(np.float64)
+    ref = reference_for('dla', model, 10, hpd, prop_W=pp[:10, None], prop_b=pp[10:])
+    rng = np.random.RandomState(1)
+    for step in range(3):
+        feed_dict, info = feed.get_batch(data, check_validation=True)
+        batch = feed_dict[DEVICE_BATCH_KEY]
+        assert (batch.labels.sum(dim=0) > 0).all()
+        t_in = torch_feed(data, batch)
+        u = tie_uniforms(model, rng, B)
+        loss, _, summary = model.step(None, feed_dict, False)
+        ref_loss, ref_sum = ref.step(*t_in, u_pred=u)
+        assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss), step
+        got = summary.as_dict()
+        for tag, val in ref_sum.items():
+            key = tag.replace(' ', '_')
+            assert key in got, key
+            assert abs(got[key] - val) <= 2e-5 * max(abs(val), 1e-2), (step, key, got[key], val)
+        assert got['Learning_Rate'] == model.hparams.learning_rate
+    tol = 3e-5  # three Adagrad steps of fp32 arithmetic against float64
+    compare_params(model, ref, tol)
+    assert relerr(model.prop_params.cpu().numpy()[:10], ref.prop_W.detach().numpy()[:, 0]) < tol
+    assert abs(model.prop_params[10].item() - ref.prop_b.item()) < tol
+    assert model.global_step.eval() == 3
+    assert len(info['input_list']) == B and len(info['click_list'][0]) == 10
+
+
+def test_numpy_reference_style_feed_gives_the_same_step():
+    """The reference's own feed format (float64 features, float32-typed doc ids, per-position arrays, q1)."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(200, 10, 16, seed=5, pad_frac=0.3)
+    exp = settings('DLA')
+    m1, feed = make('DLA', data, exp, 64)
+    m2, _ = make('DLA', data, exp, 64)
+    feed_dict, _ = feed.get_batch(data, True)
+    batch = feed_dict[DEVICE_BATCH_KEY]
+    docids, clicks = batch.docids.cpu().numpy(), batch.labels.cpu().numpy()
+    # compact the table like click_simulation_feed.py:98-104,140-143: only the batch's docs, pad id = len(table)
+    n_rows = data.features.shape[0]
+    used = np.unique(docids[docids < n_rows])
+    remap = np.full(n_rows + 1, len(used), dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    np_feed = {m2.letor_features.name: data.features[used].astype(np.float64)}
+    for l in range(10):
+        np_feed[m2.docid_inputs[l].name] = remap[docids[l]].astype(np.float32)
+        np_feed[m2.labels[l].name] = clicks[l].astype(np.float32)
+    l1, _, s1 = m1.step(None, feed_dict, False)
+    l2, _, s2 = m2.step(None, np_feed, False)
+    assert abs(float(l1) - float(l2)) < 1e-6 * abs(float(l1))
+    assert relerr(m2.model.params.cpu().numpy(), m1.model.params.cpu().numpy()) < 1e-6
+    a, b = s1.as_dict(), s2.as_dict()
+    assert a.keys() == b.keys() and all(abs(a[k] - b[k]) < 1e-5 for k in a)
+
+
+def test_ipw_steps_match_reference_graph():
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(300, 10, 20, seed=7, pad_frac=0.1)
+    exp = settings('IPWrank', 'propensity_estimator_json=%s' % IPW_JSON)
+    model, feed = make('IPWrank', data, exp, 128)
+    ref = reference_for('ipw', model, 10, {})
+    ipw = model.propensity_estimator.IPW_list
+    for step in range(3):
+        feed_dict, _ = feed.get_batch(data, True)
+        batch = feed_dict[DEVICE_BATCH_KEY]
+        table, d, c = torch_feed(data, batch)
+        clicks = batch.labels.cpu().numpy()
+        pw = [torch.tensor([O.propensity_for_one_list(ipw, list(clicks[:, b]))[l] for b in range(clicks.shape[1])])
+              for l in range(10)]
+        u = tie_uniforms(model, np.random.RandomState(step), 128)
+        loss, _, summary = model.step(None, feed_dict, False)
+        ref_loss, ref_sum = ref.step(table, d, c, pw_lists=pw, u_pred=u)
+        assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+        got = summary.as_dict()
+        for tag, val in ref_sum.items():
+            assert abs(got[tag.replace(' ', '_')] - val) <= 2e-5 * max(abs(val), 1e-2), tag
+        assert 'Propensity_weights_0' in got
+    compare_params(model, ref, 3e-5)
+
+
+def test_rem_steps_match_reference_graph():
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(300, 10, 20, seed=9)
+    exp = settings('RegressionEM', 'EM_step_size=0.1')
+    model, feed = make('RegressionEM', data, exp, 128)
+    ref = reference_for('rem', model, 10, {'EM_step_size': 0.1})
+    rng = np.random.RandomState(0)
+    for step in range(3):
+        feed_dict, _ = feed.get_batch(data, True)
+        table, d, c = torch_feed(data, feed_dict[DEVICE_BATCH_KEY])
+        u = rng.uniform(size=(10, 128)).astype(np.float32)
+        model.uniforms = torch.tensor(u).cuda()
+        ut = tie_uniforms(model, rng, 128)
+        loss, _, summary = model.step(None, feed_dict, False)
+        ref_loss, ref_sum = ref.step(table, d, c, uniforms=torch.tensor(u.T.astype(np.float64)), u_pred=ut)
+        assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+        got = summary.as_dict()
+        assert abs(got['Gradient_Norm'] - ref_sum['Gradient Norm']) < 1e-5 * ref_sum['Gradient Norm']
+        for tag in ('ndcg_10', 'Weighted_ndcg_10', 'mrr_3'):
+            assert abs(got[tag] - ref_sum[tag]) < 2e-5
+    compare_params(model, ref, 3e-5)
+    assert relerr(model.propensity.cpu().numpy(), ref.propensity.numpy()[0]) < 1e-5
+    assert abs(model.sigmoid_prob_b.item() - ref.sigmoid_prob_b.item()) < 3e-5 * max(abs(ref.sigmoid_prob_b.item()), 1e-2)
+    assert abs(got['Examination_Probability_0'] - 0.9) < 0.2
+
+
+def test_pd_steps_match_reference_graph():
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(300, 10, 20, seed=11)
+    exp = settings('PairDebias', '', feed_hparams='click_model_json=%s' % CASCADE)
+    model, feed = make('PairDebias', data, exp, 128)
+    ref = reference_for('pd', model, 10, {})
+    for step in range(3):
+        feed_dict, _ = feed.get_batch(data, True)
+        batch = feed_dict[DEVICE_BATCH_KEY]
+        assert (batch.labels.sum(dim=0) == 1).all()  # cascade: exactly one click per accepted list
+        table, d, c = torch_feed(data, batch)
+        ut = tie_uniforms(model, np.random.RandomState(step), 128)
+        loss, _, summary = model.step(None, feed_dict, False)
+        ref_loss, ref_sum = ref.step(table, d, c, u_pred=ut)
+        assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+        got = summary.as_dict()
+        assert abs(got['Gradient_Norm'] - ref_sum['Gradient Norm']) < 1e-5 * ref_sum['Gradient Norm']
+        assert 'Weighted_ndcg_10' not in got and abs(got['ndcg_5'] - ref_sum['ndcg_5']) < 2e-5
+    compare_params(model, ref, 3e-5)
+    assert relerr(model.t_plus.cpu().numpy(), ref.t_plus.numpy()[0]) < 1e-5
+    assert relerr(model.t_minus.cpu().numpy(), ref.t_minus.numpy()[0]) < 1e-5
+
+
+def test_eval_step_and_direct_label_feed():
+    from ultra_amd.utils import find_class, merge_TFSummary
+    data = SyntheticData(150, 14, 20, seed=13, pad_frac=0.4)
+    exp = settings('DLA', Lmax=14, cutoff=10)
+    model, _ = make('DLA', data, exp, 64)
+    vfeed = find_class(exp['valid_input_feed'])(model, 64, '', None)
+    it, sums, sizes, all_scores = 0, [], [], []
+    while it < len(data.initial_list):
+        feed_dict, info = vfeed.get_next_batch(it, data, check_validation=False)
+        _, scores, summary = model.step(None, feed_dict, True)
+        sums.append(summary)
+        sizes.append(len(info['input_list']))
+        all_scores.append(scores)
+        it += sizes[-1]
+    assert sizes == [64, 64, 22]
+    scores = np.concatenate(all_scores, 0)
+    assert scores.shape == (150, 14)
+    ps = [{k: v.astype(np.float64) for k, v in p.items()} for p in model.model.unflatten(model.model.params)]
+    n_rows = data.features.shape[0]
+    docids = np.where(data.initial_list < 0, n_rows, data.initial_list)
+    ref, _ = O.dnn_forward(ps, O.gather_rows(data.features.astype(np.float64), docids.reshape(-1)))
+    ref = ref.reshape(150, 14)
+    assert relerr(scores, ref) < 1e-5
+    merged = merge_TFSummary(sums, sizes).as_dict()
+    labels = np.where(data.initial_list < 0, 0, data.labels).astype(np.float64)
+    masked = O.remove_padding(ref, docids, n_rows)
+    assert abs(merged['ndcg_10'] - O.ndcg(labels, masked, None, 10)) < 2e-5
+    assert abs(merged['mrr_3'] - O.mrr(labels, masked)) < 2e-5
+    assert list(merged) == ['mrr_3', 'mrr_5', 'mrr_10', 'ndcg_3', 'ndcg_5', 'ndcg_10']
+
+
+def test_python_rng_feed_is_bit_exact_with_the_reference_stream():
+    """device_rng=False: the batch and the post-call state of Python's `random` equal what the reference's
+    get_batch produces/leaves (click_simulation_feed.py:131-137; q2)."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    import json
+    data = SyntheticData(120, 10, 8, seed=17, pad_frac=0.2)
+    exp = settings('DLA', feed_hparams='click_model_json=%s,device_rng=False' % PBM)
+    model, feed = make('DLA', data, exp, 200)
+    g = json.load(open(PBM))
+    random.seed(1234)
+    feed_dict, info = feed.get_batch(data, check_validation=True)
+    after = random.random()
+    random.seed(1234)
+    u = [random.random() for _ in range(200 * 11 * 8)]
+    idxs, clicks, n_cand = O.get_batch_sequential(data.initial_list, data.labels, 10, 200, g['model_name'],
+                                                  g['click_prob'], g['exam_prob'], u, True)
+    assert [x[0] for x in info['rank_list_idxs']] == idxs
+    assert np.array_equal(feed_dict[DEVICE_BATCH_KEY].labels.cpu().numpy().T, np.array(clicks, dtype=np.float32))
+    assert after == u[n_cand * 11]  # exactly n_cand * (1 + L) draws were consumed
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    data = SyntheticData(100, 10, 12, seed=19)
+    exp = settings('RegressionEM')
+    m1, feed = make('RegressionEM', data, exp, 32)
+    for _ in range(2):
+        m1.step(None, feed.get_batch(data, True)[0], False)
+    path = m1.saver.save(None, str(tmp_path / 'RegressionEM.ckpt'), global_step=m1.global_step)
+    m2, _ = make('RegressionEM', data, exp, 32)
+    m2.saver.restore(None, path)
+    assert torch.equal(m1.model.params, m2.model.params) and torch.equal(m1.acc, m2.acc)
+    assert torch.equal(m1.propensity, m2.propensity) and m2.global_step.eval() == 2
+
+
+def test_error_behaviour():
+    from ultra_amd.utils import find_class
+    data = SyntheticData(50, 6, 12, seed=23)
+    exp = settings('DLA', Lmax=10, cutoff=10)
+    model, feed = make('DLA', data, exp, 8)
+    with pytest.raises(ValueError):  # lists shorter than rank_list_size (click_simulation_feed.py:124-126)
+        feed.get_batch(data, True)
+    with pytest.raises(NameError):   # loss_func=pairwise_loss cannot build in the reference either
+        find_class(exp['learning_algorithm'])(data, settings('DLA', 'loss_func=pairwise_loss'), False)
+    with pytest.raises(ImportError):
+        find_class('ultra_amd.ranking_model.NoSuchModel')

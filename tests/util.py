@@ -46,3 +46,10 @@ class SyntheticData(object):
 def relerr(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def relerr_floor(a, b, floor=1e-4):
+    """L2-relative error with an absolute floor of `floor` per element: tensors whose true value is identically
+    zero (e.g. the output-layer beta under a shift-invariant loss) are compared on an absolute scale."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), floor * np.sqrt(b.size)))

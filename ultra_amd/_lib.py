@@ -55,6 +55,8 @@ _DESC = ctypes.POINTER(UltrDnnDesc)
 SIGNATURES = {
     'ultr_version': (_I, []),
     'ultr_last_error': (ctypes.c_char_p, []),
+    'ultr_profile_enable': (_I, [_I]),
+    'ultr_profile_report': (_I, [ctypes.c_char_p, _I]),
     'ultr_ln_row_stats': (_I, [_P, _LL, _I, _I, _F, _P, _P]),
     'ultr_click_pbm': (_I, [_P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),
     'ultr_click_cascade': (_I, [_P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),

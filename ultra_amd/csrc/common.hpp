@@ -21,6 +21,22 @@ int check_launch(const char* what);
     }                                          \
   } while (0)
 
+// ---- opt-in per-kernel timing (ultr_profile_enable): HIP events around every launch, on the launch
+// stream.  Off by default: one predictable branch per launch.
+extern bool g_profile_on;
+void profile_begin(const char* name, hipStream_t s, void** handle);
+void profile_end(void* handle, hipStream_t s);
+struct ProfScope {
+  void* h;
+  hipStream_t s;
+  ProfScope(const char* name, hipStream_t st) : h(nullptr), s(st) {
+    if (g_profile_on) profile_begin(name, st, &h);
+  }
+  ~ProfScope() {
+    if (h) profile_end(h, s);
+  }
+};
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 

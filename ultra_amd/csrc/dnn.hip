@@ -24,7 +24,7 @@ namespace ultr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 16;        // contraction chunk per LDS stage
+constexpr int BK = 32;        // contraction chunk per LDS stage (16 MFMA steps of K=2)
 constexpr int LDK = BK + 4;   // row stride of a k-contiguous LDS tile (conflict-free ds_read_b128)
 constexpr int kThreads = 256; // 4 waves
 
@@ -147,23 +147,45 @@ __device__ __forceinline__ float2 merge_partials(const float* __restrict__ part,
 
 // ---------------------------------------------------------------------------------------------
 // MFMA micro-kernels.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and
-// B[k = l>>5][j = l&31]; over the 8 steps of a BK=16 chunk, lane half h walks k = 8h + t.
+// B[k = l>>5][j = l&31]; over the 16 steps of a BK=32 chunk, lane half h walks k = 16h + t.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_frag_kcontig(const float* __restrict__ tile, int row, int h, float (&f)[8]) {
-  const float4 v0 = *reinterpret_cast<const float4*>(tile + row * LDK + 8 * h);
-  const float4 v1 = *reinterpret_cast<const float4*>(tile + row * LDK + 8 * h + 4);
-  f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
-  f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+__device__ __forceinline__ void load_frag_kcontig(const float* __restrict__ tile, int row, int h, float (&f)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(tile + row * LDK + 16 * h + 4 * q);
+    f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+  }
 }
 __device__ __forceinline__ void load_frag_kmajor(const float* __restrict__ tile, int ld, int col, int h,
-                                                 float (&f)[8]) {
+                                                 float (&f)[16]) {
 #pragma unroll
-  for (int t = 0; t < 8; ++t) f[t] = tile[(8 * h + t) * ld + col];
+  for (int t = 0; t < 16; ++t) f[t] = tile[(16 * h + t) * ld + col];
 }
-__device__ __forceinline__ void mma8(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+__device__ __forceinline__ void mma16(const float (&a)[16], const float (&b)[16], f32x16& acc) {
 #pragma unroll
-  for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+  for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
 }
+// Software pipeline shared by the three GEMM kernels: two register stages keep TWO chunks of global
+// loads in flight while a third is being multiplied out of LDS (one workgroup per CU has no other
+// waves to hide the L2 latency behind).  LOAD(chunk, regs), STORE(regs, buf), COMPUTE(buf).
+#define ULTR_GEMM_PIPELINE(NCHUNK, LOAD, STORE, COMPUTE)  \
+  do {                                                    \
+    if ((NCHUNK) > 0) LOAD(0, R0);                        \
+    if ((NCHUNK) > 1) LOAD(1, R1);                        \
+    if ((NCHUNK) > 0) STORE(R0, 0);                       \
+    __syncthreads();                                      \
+    for (int c_ = 0; c_ < (NCHUNK); c_ += 2) {            \
+      if (c_ + 2 < (NCHUNK)) LOAD(c_ + 2, R0);            \
+      COMPUTE(0);                                         \
+      if (c_ + 1 < (NCHUNK)) STORE(R1, 1);                \
+      __syncthreads();                                    \
+      if (c_ + 1 >= (NCHUNK)) break;                      \
+      if (c_ + 3 < (NCHUNK)) LOAD(c_ + 3, R1);            \
+      COMPUTE(1);                                         \
+      if (c_ + 2 < (NCHUNK)) STORE(R0, 0);                \
+      __syncthreads();                                    \
+    }                                                     \
+  } while (0)
 // accumulator register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -187,12 +209,18 @@ struct FwdArgs {
   int activation;
   float* act_out;          // [M][ldn]
   float* part_out;         // [M][ntile_out][2]
+  // fused output layer (only when N <= 128, i.e. one column tile owns complete rows):
+  //   score[m] = LN(act_m) . out_W + out_b ; out_stat[m] = (mean, rstd) of act_m
+  int fuse_out;
+  const float* out_gamma; const float* out_beta; const float* out_W; const float* out_bias;
+  float* out_stat; float* scores;
 };
 
 __global__ void __launch_bounds__(kThreads) fwd_layer_kernel(FwdArgs p) {
   __shared__ __attribute__((aligned(16))) float As[2][32 * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * 128];
   __shared__ float s_stat[32][2];
+  __shared__ float s_red[32][4][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const long long m0 = (long long)blockIdx.x * 32;
   const int n0 = blockIdx.y * 128;
@@ -218,78 +246,85 @@ __global__ void __launch_bounds__(kThreads) fwd_layer_kernel(FwdArgs p) {
   }
   __syncthreads();
 
-  // --- staging assignments
-  // A: 32 rows x 16 k = 128 float4 -> threads 0..127: row = tid/4, quad = tid%4
-  const int a_row = tid >> 2, a_q = tid & 3;
-  const bool a_thread = tid < 128;
+  // --- staging: A 32 rows x 32 k = 256 float4 (one per thread); B 32 k x 128 cols = 1024 float4 (four).
+  // Every global load is UNCONDITIONAL on a clamped (always valid) address and masked afterwards: a load
+  // under a divergent branch makes hipcc wait for it at the end of the branch (vmcnt(0)), which serialises
+  // the whole stage on memory latency.
+  const int a_row = tid >> 3, a_q = tid & 7;
   const long long a_m = m0 + a_row;
-  const float* a_src = nullptr;
-  float a_mean = 0.f, a_rstd = 1.f;
-  if (a_thread && a_m < p.M) {
+  bool a_live = a_m < p.M;
+  const float* a_src = p.x;
+  {
+    const long long mc = a_live ? a_m : p.M - 1;
     if (p.docids) {
-      const int d = p.docids[a_m];
-      a_src = d < p.n_rows ? p.x + (long long)d * p.ldx : nullptr;  // pad row: zeros
+      const int d = p.docids[mc];
+      if (d < p.n_rows) a_src = p.x + (long long)d * p.ldx;
+      else a_live = a_live && p.has_ln;  // pad row: x = 0 (LayerNorm of it is beta, handled by the stats entry)
+      if (d >= p.n_rows) a_src = nullptr;
     } else {
-      a_src = p.x + a_m * p.ldx;
+      a_src = p.x + mc * p.ldx;
     }
-    a_mean = s_stat[a_row][0];
-    a_rstd = s_stat[a_row][1];
   }
-  const bool a_live = a_thread && a_m < p.M;
-  // B: 16 k x 128 cols = 512 float4 -> 2 per thread: f = tid + 256*i, row = f/32, c4 = f%32
-  float4 ra, rb0, rb1;
-  auto load_chunk = [&](int k0) {
-    ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ka = k0 + 4 * a_q;
-    if (a_live && ka < p.K) {
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_src) x = *reinterpret_cast<const float4*>(a_src + ka);
-      if (p.has_ln) {
-        const float4 g = *reinterpret_cast<const float4*>(p.gamma + ka);
-        const float4 b = *reinterpret_cast<const float4*>(p.beta + ka);
-        x.x = (x.x - a_mean) * a_rstd * g.x + b.x;
-        x.y = (x.y - a_mean) * a_rstd * g.y + b.y;
-        x.z = (x.z - a_mean) * a_rstd * g.z + b.z;
-        x.w = (x.w - a_mean) * a_rstd * g.w + b.w;
-      }
-      // k beyond K inside this quad -> 0 (the row stride is padded, the values are not ours)
-      if (ka + 1 >= p.K) x.y = 0.f;
-      if (ka + 2 >= p.K) x.z = 0.f;
-      if (ka + 3 >= p.K) x.w = 0.f;
-      ra = x;
+  const bool a_pad = a_src == nullptr;   // zero feature row
+  if (a_pad) a_src = p.x;
+  const float a_mean = s_stat[a_row][0], a_rstd = s_stat[a_row][1];
+  const int k_last4 = ((p.K + 3) & ~3) - 4, x_last4 = p.ldx - 4, n_last4 = p.ldn - 4;
+  struct Regs {
+    float4 a, g, bt, b[4];
+    int ka;
+  } R0, R1;
+  auto load_chunk = [&](int chunk, Regs& r) {
+    const int k0 = chunk * BK;
+    r.ka = k0 + 4 * a_q;
+    r.a = *reinterpret_cast<const float4*>(a_src + min(r.ka, x_last4));
+    if (p.has_ln) {
+      r.g = *reinterpret_cast<const float4*>(p.gamma + min(r.ka, k_last4));
+      r.bt = *reinterpret_cast<const float4*>(p.beta + min(r.ka, k_last4));
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int f = tid + 256 * i;
-      const int row = f >> 5, c = n0 + 4 * (f & 31);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + row < p.K && c < p.ldn) v = *reinterpret_cast<const float4*>(p.W + (long long)(k0 + row) * p.ldn + c);
-      if (i == 0) rb0 = v; else rb1 = v;
+      const int row = min(k0 + (f >> 5), p.K - 1), c = min(n0 + 4 * (f & 31), n_last4);
+      r.b[i] = *reinterpret_cast<const float4*>(p.W + (long long)row * p.ldn + c);
     }
   };
-  auto store_chunk = [&](int buf) {
-    if (a_thread) *reinterpret_cast<float4*>(&As[buf][a_row * LDK + 4 * a_q]) = ra;
-    *reinterpret_cast<float4*>(&Bs[buf][(tid >> 5) * 128 + 4 * (tid & 31)]) = rb0;
-    *reinterpret_cast<float4*>(&Bs[buf][((tid + 256) >> 5) * 128 + 4 * (tid & 31)]) = rb1;
+  auto store_chunk = [&](Regs& r, int buf) {
+    float4 x = a_pad ? make_float4(0.f, 0.f, 0.f, 0.f) : r.a;
+    if (p.has_ln) {  // LayerNorm applied while staging: (x - mean) * rstd * gamma + beta
+      x.x = (x.x - a_mean) * a_rstd * r.g.x + r.bt.x;
+      x.y = (x.y - a_mean) * a_rstd * r.g.y + r.bt.y;
+      x.z = (x.z - a_mean) * a_rstd * r.g.z + r.bt.z;
+      x.w = (x.w - a_mean) * a_rstd * r.g.w + r.bt.w;
+    }
+    // rows beyond M and k beyond K contribute nothing
+    if (!a_live || r.ka >= p.K) x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r.ka + 1 >= p.K) x.y = 0.f;
+    if (r.ka + 2 >= p.K) x.z = 0.f;
+    if (r.ka + 3 >= p.K) x.w = 0.f;
+    *reinterpret_cast<float4*>(&As[buf][a_row * LDK + 4 * a_q]) = x;
+    const int kb = r.ka - 4 * a_q;  // k0 of the chunk these registers hold
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      float4 v = r.b[i];
+      if (kb + (f >> 5) >= p.K || n0 + 4 * (f & 31) >= p.ldn) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&Bs[buf][(f >> 5) * 128 + 4 * (f & 31)]) = v;
+    }
   };
-
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nchunk = (p.K + BK - 1) / BK;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunk) load_chunk((c + 1) * BK);
-    float a[8], b[8];
+  auto compute = [&](int buf) {
+    float a[16], b[16];
     load_frag_kcontig(As[buf], l31, h, a);
     load_frag_kmajor(Bs[buf], 128, w * 32 + l31, h, b);
-    mma8(a, b, acc);
-    if (c + 1 < nchunk) store_chunk(buf ^ 1);
-    __syncthreads();
-  }
+    mma16(a, b, acc);
+  };
+  const int nchunk = (p.K + BK - 1) / BK;
+#define FWD_LOAD(c, R) load_chunk(c, R)
+#define FWD_STORE(R, b) store_chunk(R, b)
+#define FWD_COMPUTE(b) compute(b)
+  ULTR_GEMM_PIPELINE(nchunk, FWD_LOAD, FWD_STORE, FWD_COMPUTE);
 
   // --- epilogue: bias + activation + store + partial LayerNorm statistics of the output rows
   const int col = n0 + w * 32 + l31;
@@ -298,22 +333,68 @@ __global__ void __launch_bounds__(kThreads) fwd_layer_kernel(FwdArgs p) {
   const bool col_ok = col < p.N;
   const float bias = col_ok ? p.bias[col] : 0.f;
   const int ntile_out = (p.N + 31) >> 5;
+  float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const long long m = m0 + acc_row(r, h);
-    float v = col_ok ? act_fwd(p.activation, acc[r] + bias) : 0.f;
-    if (m < p.M && col < p.ldn) p.act_out[m * p.ldn + col] = v;
+    v[r] = col_ok ? act_fwd(p.activation, acc[r] + bias) : 0.f;
+    if (m < p.M && col < p.ldn) p.act_out[m * p.ldn + col] = v[r];
+    float sum = 0.f, m2 = 0.f;
     if (cnt > 0) {
-      const float sum = half_sum(v);
+      sum = half_sum(v[r]);
       const float mu = sum / (float)cnt;
-      const float dv = col_ok ? v - mu : 0.f;
-      const float m2 = half_sum(dv * dv);
+      const float dv = col_ok ? v[r] - mu : 0.f;
+      m2 = half_sum(dv * dv);
       if (l31 == 0 && m < p.M) {
         float* dst = p.part_out + (m * ntile_out + (colbase >> 5)) * 2;
         dst[0] = sum;
         dst[1] = m2;
       }
     }
+    if (p.fuse_out && l31 == 0) {
+      s_red[acc_row(r, h)][w][0] = sum;
+      s_red[acc_row(r, h)][w][1] = m2;
+    }
+  }
+  if (!p.fuse_out) return;
+
+  // --- fused output layer: this block holds complete rows (N <= 128)
+  __syncthreads();
+  if (tid < 32) {  // merge the (up to 4) column-group partials of each row, Chan's formula as merge_partials
+    float total = 0.f;
+    for (int g = 0; g < ntile_out; ++g) total += s_red[tid][g][0];
+    const float mean = total / (float)p.N;
+    float m2 = 0.f;
+    for (int g = 0; g < ntile_out; ++g) {
+      const int c = min(32, p.N - 32 * g);
+      const float d = s_red[tid][g][0] / (float)c - mean;
+      m2 += s_red[tid][g][1] + (float)c * d * d;
+    }
+    float2 st = make_float2(0.f, 1.f);
+    if (p.has_ln) st = make_float2(mean, 1.f / sqrtf(m2 / (float)p.N + p.eps));
+    s_stat[tid][0] = st.x;
+    s_stat[tid][1] = st.y;
+    if (m0 + tid < p.M && p.has_ln) {
+      p.out_stat[2 * (m0 + tid)] = st.x;
+      p.out_stat[2 * (m0 + tid) + 1] = st.y;
+    }
+  }
+  __syncthreads();
+  const float og = (col_ok && p.has_ln) ? p.out_gamma[col] : 1.f;
+  const float ob = (col_ok && p.has_ln) ? p.out_beta[col] : 0.f;
+  const float ow = col_ok ? p.out_W[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, h);
+    const float hk = col_ok ? ((v[r] - s_stat[row][0]) * s_stat[row][1] * og + ob) * ow : 0.f;
+    const float part = half_sum(hk);
+    if (l31 == 0) s_red[row][w][0] = part;
+  }
+  __syncthreads();
+  if (tid < 32 && m0 + tid < p.M) {
+    float sc = p.out_bias[0];
+    for (int g = 0; g < 4; ++g) sc += (g < ntile_out) ? s_red[tid][g][0] : 0.f;
+    p.scores[m0 + tid] = sc;
   }
 }
 
@@ -463,69 +544,77 @@ __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) {
   const long long m_begin = (long long)blockIdx.z * p.rows_per_split;
   long long m_end = m_begin + p.rows_per_split;
   if (m_end > p.M) m_end = p.M;
-  const int s_row = tid >> 4, s_c = 4 * (tid & 15);  // staging: 16 rows x 16 float4
-  float4 ra, rb;
-  auto load_chunk = [&](long long mc) {
-    const long long m = mc + s_row;
-    ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    rb = ra;
-    if (m < m_end) {
-      const int ka = k0 + s_c;
-      if (ka < p.K) {
-        const float* src;
-        float2 st = make_float2(0.f, 1.f);
-        if (p.docids) {
-          const int d = p.docids[m];
-          src = d < p.n_rows ? p.x + (long long)d * p.ldx : nullptr;
-          if (p.has_ln) st = make_float2(p.row_stats[2 * (long long)d], p.row_stats[2 * (long long)d + 1]);
-        } else {
-          src = p.x + m * p.ldx;
-          if (p.has_ln) st = make_float2(p.stat_in[2 * m], p.stat_in[2 * m + 1]);
-        }
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (src) x = *reinterpret_cast<const float4*>(src + ka);
-        if (p.has_ln) {
-          x.x = (x.x - st.x) * st.y; x.y = (x.y - st.x) * st.y;
-          x.z = (x.z - st.x) * st.y; x.w = (x.w - st.x) * st.y;
-        }
-        if (ka + 1 >= p.K) x.y = 0.f;
-        if (ka + 2 >= p.K) x.z = 0.f;
-        if (ka + 3 >= p.K) x.w = 0.f;
-        ra = x;
+  // staging: 32 rows x 16 float4 per operand = 512 float4 -> two per thread (rows s_row and s_row + 16)
+  const int s_row = tid >> 4, s_c = 4 * (tid & 15);
+  struct Regs {
+    float4 a[2], b[2];
+    float2 st[2];
+    long long m[2];
+  } R0, R1;
+  const int ka = k0 + s_c, nb = n0 + s_c;
+  const int kac = min(ka, p.ldx - 4), nbc = min(nb, p.ldn - 4);
+  auto load_chunk = [&](int chunk, Regs& r) {  // unconditional loads on clamped addresses, masked at store time
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long m = m_begin + (long long)chunk * BK + s_row + 16 * i;
+      r.m[i] = m;
+      const long long mc = m < m_end ? m : m_end - 1;
+      long long xrow = mc, srow = mc;
+      bool pad = false;
+      if (p.docids) {
+        const int d = p.docids[mc];
+        pad = d >= p.n_rows;
+        xrow = pad ? 0 : d;
+        srow = d;
       }
-      const int nb = n0 + s_c;
-      if (nb < p.ldn) rb = *reinterpret_cast<const float4*>(p.dz + m * p.ldn + nb);
+      r.a[i] = *reinterpret_cast<const float4*>(p.x + xrow * p.ldx + kac);
+      r.st[i] = make_float2(0.f, 1.f);
+      if (p.has_ln) {
+        const float* sp = p.docids ? p.row_stats : p.stat_in;
+        r.st[i] = *reinterpret_cast<const float2*>(sp + 2 * srow);
+      }
+      if (pad) r.st[i] = make_float2(0.f, 0.f), r.a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      r.b[i] = *reinterpret_cast<const float4*>(p.dz + mc * p.ldn + nbc);
     }
   };
-  auto store_chunk = [&](int buf) {
-    *reinterpret_cast<float4*>(&As[buf][s_row * 64 + s_c]) = ra;
-    *reinterpret_cast<float4*>(&Bs[buf][s_row * 64 + s_c]) = rb;
+  auto store_chunk = [&](Regs& r, int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 x = r.a[i];
+      const float mean = r.st[i].x, rstd = r.st[i].y;  // xhat = (x - mean) * rstd  (mean 0, rstd 1 without LN)
+      x.x = (x.x - mean) * rstd; x.y = (x.y - mean) * rstd;
+      x.z = (x.z - mean) * rstd; x.w = (x.w - mean) * rstd;
+      float4 dzv = r.b[i];
+      const bool row_ok = r.m[i] < m_end;
+      if (!row_ok || ka >= p.K) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ka + 1 >= p.K) x.y = 0.f;
+      if (ka + 2 >= p.K) x.z = 0.f;
+      if (ka + 3 >= p.K) x.w = 0.f;
+      if (!row_ok || nb >= p.ldn) dzv = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&As[buf][(s_row + 16 * i) * 64 + s_c]) = x;
+      *reinterpret_cast<float4*>(&Bs[buf][(s_row + 16 * i) * 64 + s_c]) = dzv;
+    }
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float colsum = 0.f;
   const bool do_colsum = blockIdx.x == 0 && tid < 64;
-  const int nchunk = (int)((m_end - m_begin + BK - 1) / BK);
-  if (nchunk > 0) {
-    load_chunk(m_begin);
-    store_chunk(0);
-  }
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunk) load_chunk(m_begin + (long long)(c + 1) * BK);
-    float a[8], b[8];
+  auto compute = [&](int buf) {
+    float a[16], b[16];
     load_frag_kmajor(As[buf], 64, wr * 32 + l31, h, a);
     load_frag_kmajor(Bs[buf], 64, wc * 32 + l31, h, b);
-    mma8(a, b, acc);
+    mma16(a, b, acc);
     if (do_colsum) {
 #pragma unroll
       for (int r = 0; r < BK; ++r) colsum += Bs[buf][r * 64 + tid];
     }
-    if (c + 1 < nchunk) store_chunk(buf ^ 1);
-    __syncthreads();
-  }
+  };
+  const int nchunk = (int)((m_end - m_begin + BK - 1) / BK);
+#define WG_LOAD(c, R) load_chunk(c, R)
+#define WG_STORE(R, b) store_chunk(R, b)
+#define WG_COMPUTE(b) compute(b)
+  ULTR_GEMM_PIPELINE(nchunk, WG_LOAD, WG_STORE, WG_COMPUTE);
   float* g = p.gslab + (long long)blockIdx.z * p.K * p.ldn;
   const int col = n0 + wc * 32 + l31;
 #pragma unroll
@@ -553,46 +642,49 @@ __global__ void __launch_bounds__(kThreads) dgrad_kernel(DgradArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const long long m0 = (long long)blockIdx.x * 32;
   const int k0 = blockIdx.y * 128;
-  const int a_row = tid >> 2, a_q = tid & 3;
-  const bool a_thread = tid < 128;
-  float4 ra, rb0, rb1;
-  auto load_chunk = [&](int n0) {
-    ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int na = n0 + 4 * a_q;
-    if (a_thread && m0 + a_row < p.M && na < p.ldn)
-      ra = *reinterpret_cast<const float4*>(p.dz + (m0 + a_row) * p.ldn + na);
+  const int a_row = tid >> 3, a_q = tid & 7;  // A: 32 rows x 8 quads; B: 128 rows x 8 quads = 4 per thread
+  struct Regs {
+    float4 a, b[4];
+    int n0;
+  } R0, R1;
+  const long long a_mc = (m0 + a_row < p.M) ? m0 + a_row : p.M - 1;
+  const int n_last4 = p.ldn - 4;
+  auto load_chunk = [&](int chunk, Regs& r) {  // unconditional loads on clamped addresses, masked at store time
+    r.n0 = chunk * BK;
+    r.a = *reinterpret_cast<const float4*>(p.dz + a_mc * p.ldn + min(r.n0 + 4 * a_q, n_last4));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int f = tid + 256 * i;  // 128 rows x 4 quads
-      const int row = f >> 2, q = f & 3;
-      const int nb = n0 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + row < p.K && nb < p.ldn) v = *reinterpret_cast<const float4*>(p.W + (long long)(k0 + row) * p.ldn + nb);
-      if (i == 0) rb0 = v; else rb1 = v;
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int row = min(k0 + (f >> 3), p.K - 1), nb = min(r.n0 + 4 * (f & 7), n_last4);
+      r.b[i] = *reinterpret_cast<const float4*>(p.W + (long long)row * p.ldn + nb);
     }
   };
-  auto store_chunk = [&](int buf) {
-    if (a_thread) *reinterpret_cast<float4*>(&As[buf][a_row * LDK + 4 * a_q]) = ra;
-    *reinterpret_cast<float4*>(&Bs[buf][(tid >> 2) * LDK + 4 * (tid & 3)]) = rb0;
-    *reinterpret_cast<float4*>(&Bs[buf][((tid + 256) >> 2) * LDK + 4 * (tid & 3)]) = rb1;
+  auto store_chunk = [&](Regs& r, int buf) {
+    float4 av = r.a;
+    if (m0 + a_row >= p.M || r.n0 + 4 * a_q >= p.ldn) av = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&As[buf][a_row * LDK + 4 * a_q]) = av;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      float4 v = r.b[i];
+      if (k0 + (f >> 3) >= p.K || r.n0 + 4 * (f & 7) >= p.ldn) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&Bs[buf][(f >> 3) * LDK + 4 * (f & 7)]) = v;
+    }
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nchunk = (p.N + BK - 1) / BK;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunk) load_chunk((c + 1) * BK);
-    float a[8], b[8];
+  auto compute = [&](int buf) {
+    float a[16], b[16];
     load_frag_kcontig(As[buf], l31, h, a);
     load_frag_kcontig(Bs[buf], w * 32 + l31, h, b);
-    mma8(a, b, acc);
-    if (c + 1 < nchunk) store_chunk(buf ^ 1);
-    __syncthreads();
-  }
+    mma16(a, b, acc);
+  };
+  const int nchunk = (p.N + BK - 1) / BK;
+#define DG_LOAD(c, R) load_chunk(c, R)
+#define DG_STORE(R, b) store_chunk(R, b)
+#define DG_COMPUTE(b) compute(b)
+  ULTR_GEMM_PIPELINE(nchunk, DG_LOAD, DG_STORE, DG_COMPUTE);
   const int col = k0 + w * 32 + l31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -683,11 +775,24 @@ __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
   const float bet = p.has_ln ? p.params[p.off_beta[j] + k] : 0.f;
   float v[2] = {0.f, 0.f};
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    float G = 0.f, S = 0.f;
-    for (int s = 0; s < ns; ++s) {
-      G += p.gslab[j][((long long)s * p.K[j] + k) * ldn + n];
-      S += p.sslab[j][(long long)s * ldn + n];
+    // slabs are summed in a fixed order; 4 independent partial sums keep 8 loads in flight
+    float G4[4] = {0.f, 0.f, 0.f, 0.f}, S4[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* gp = p.gslab[j] + (long long)k * ldn + n;
+    const float* sp = p.sslab[j] + n;
+    const long long gstride = (long long)p.K[j] * ldn;
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        G4[q] += gp[(long long)(s + q) * gstride];
+        S4[q] += sp[(long long)(s + q) * ldn];
+      }
     }
+    for (; s < ns; ++s) {
+      G4[0] += gp[(long long)s * gstride];
+      S4[0] += sp[(long long)s * ldn];
+    }
+    const float G = (G4[0] + G4[1]) + (G4[2] + G4[3]), S = (S4[0] + S4[1]) + (S4[2] + S4[3]);
     dW[n] = gam * G + bet * S;
     const float wv = W[n];
     v[0] += wv * G;
@@ -738,8 +843,11 @@ extern "C" int ultr_ln_row_stats(const float* x, long long n_rows, int F, int ld
   ULTR_REQUIRE(x && stats, ULTR_EINVAL, "ultr_ln_row_stats: null pointer");
   ULTR_REQUIRE(n_rows >= 0 && F > 0 && ldx >= F, ULTR_EINVAL, "ultr_ln_row_stats: bad sizes n_rows=%lld F=%d ldx=%d",
                n_rows, F, ldx);
-  hipLaunchKernelGGL(ln_row_stats_kernel, dim3((unsigned)cdiv(n_rows + 1, 4)), dim3(kThreads), 0, as_stream(stream), x,
+  {
+    ultr::ProfScope prof_("ln_row_stats_kernel", as_stream(stream));
+    hipLaunchKernelGGL(ln_row_stats_kernel, dim3((unsigned)cdiv(n_rows + 1, 4)), dim3(kThreads), 0, as_stream(stream), x,
                      n_rows, F, ldx, eps, stats);
+  }
   return check_launch("ln_row_stats_kernel");
 }
 
@@ -783,11 +891,21 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
     a.W = params + desc->off_W[j]; a.bias = params + desc->off_b[j];
     a.K = L.K[j]; a.N = L.N[j]; a.ldn = L.ldn[j]; a.M = M; a.activation = desc->activation;
     a.act_out = ws + L.act[j]; a.part_out = ws + L.part[j];
-    hipLaunchKernelGGL(fwd_layer_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.N[j], 128)), dim3(kThreads), 0,
+    if (j == L.H - 1 && L.N[j] <= 128) {  // the last hidden layer also produces the scores
+      a.fuse_out = 1;
+      a.out_gamma = params + desc->off_gamma[L.H]; a.out_beta = params + desc->off_beta[L.H];
+      a.out_W = params + desc->off_W[L.H]; a.out_bias = params + desc->off_b[L.H];
+      a.out_stat = ws + L.stat[L.H]; a.scores = scores;
+    }
+    {
+      ultr::ProfScope prof_("fwd_layer_kernel", st);
+      hipLaunchKernelGGL(fwd_layer_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.N[j], 128)), dim3(kThreads), 0,
                        st, a);
+    }
     rc = check_launch("fwd_layer_kernel");
     if (rc) return rc;
   }
+  if (L.H > 0 && L.N[L.H - 1] <= 128) return ULTR_OK;  // scores came out of the fused epilogue
   OutArgs o{};
   const int j = L.H;
   if (j == 0) {
@@ -799,7 +917,10 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
   o.gamma = params + desc->off_gamma[j]; o.beta = params + desc->off_beta[j];
   o.W = params + desc->off_W[j]; o.bias = params + desc->off_b[j];
   o.K = L.K[j]; o.M = M; o.scores = scores;
-  hipLaunchKernelGGL(fwd_out_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, o);
+  {
+    ultr::ProfScope prof_("fwd_out_kernel", st);
+    hipLaunchKernelGGL(fwd_out_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, o);
+  }
   return check_launch("fwd_out_kernel");
 }
 
@@ -837,7 +958,10 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
     b.rows_per_block = L.out_rows_per_block; b.partials = ws + L.outpart;
     const size_t smem = sizeof(float) * 4 * (3 * (size_t)L.K[H] + 1);
     ULTR_REQUIRE(smem <= 64 * 1024, ULTR_ELIMIT, "ultr_dnn_backward: output layer input width %d too large", L.K[H]);
-    hipLaunchKernelGGL(bwd_out_kernel, dim3((unsigned)L.out_blocks), dim3(kThreads), smem, st, b);
+    {
+      ultr::ProfScope prof_("bwd_out_kernel", st);
+      hipLaunchKernelGGL(bwd_out_kernel, dim3((unsigned)L.out_blocks), dim3(kThreads), smem, st, b);
+    }
     rc = check_launch("bwd_out_kernel");
     if (rc) return rc;
   }
@@ -852,8 +976,11 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
     g.dz = ws + L.dz[cur]; g.ldn = L.ldn[j]; g.N = L.N[j];
     g.K = L.K[j]; g.M = M; g.rows_per_split = L.rows_per_split[j];
     g.gslab = ws + L.gslab[j]; g.sslab = ws + L.sslab[j];
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64), (unsigned)L.nsplit[j]),
+    {
+      ultr::ProfScope prof_("wgrad_kernel", st);
+      hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64), (unsigned)L.nsplit[j]),
                        dim3(kThreads), 0, st, g);
+    }
     rc = check_launch("wgrad_kernel");
     if (rc) return rc;
     if (j > 0) {
@@ -862,15 +989,21 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       d.W = params + desc->off_W[j];
       d.K = L.K[j]; d.ldk = L.ldn[j - 1]; d.M = M;
       d.dh = ws + L.dz[cur ^ 1];
-      hipLaunchKernelGGL(dgrad_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128)), dim3(kThreads), 0,
+      {
+        ultr::ProfScope prof_("dgrad_kernel", st);
+        hipLaunchKernelGGL(dgrad_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128)), dim3(kThreads), 0,
                          st, d);
+      }
       rc = check_launch("dgrad_kernel");
       if (rc) return rc;
       RowpassArgs r{};
       r.dh = ws + L.dz[cur ^ 1]; r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
       r.a = ws + L.act[j - 1]; r.stat = ws + L.stat[j]; r.gamma = params + desc->off_gamma[j];
       r.has_ln = has_ln; r.activation = desc->activation;
-      hipLaunchKernelGGL(rowpass_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, r);
+      {
+        ultr::ProfScope prof_("rowpass_kernel", st);
+        hipLaunchKernelGGL(rowpass_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, r);
+      }
       rc = check_launch("rowpass_kernel");
       if (rc) return rc;
       cur ^= 1;
@@ -892,6 +1025,9 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
   }
   f.params = params; f.grads = grads; f.has_ln = has_ln;
   f.outpart = ws + L.outpart; f.out_blocks = L.out_blocks; f.Kout = L.K[H];
-  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(start + 1)), dim3(kThreads), 0, st, f);
+  {
+    ultr::ProfScope prof_("finalize_kernel", st);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(start + 1)), dim3(kThreads), 0, st, f);
+  }
   return check_launch("finalize_kernel");
 }

@@ -99,7 +99,8 @@ __device__ __forceinline__ void emit_slot(int slot, int i, unsigned long long ma
   out_list_idx[slot] = i;
 }
 
-// mode 0: one thread per slot, own Philox stream, bounded retry loop
+// mode 0: one WAVE per slot (lane r = rank r), own Philox stream, bounded retry loop.  A thread-per-slot
+// loop would chain ~2.5 attempts x L dependent gathers; here one attempt is one round trip.
 __global__ void __launch_bounds__(256) assemble_slots_kernel(const int* __restrict__ initial_list,
                                                              const float* __restrict__ labels, int Q, int Lmax, int L,
                                                              int B, int click_model, ClickTables t,
@@ -109,28 +110,54 @@ __global__ void __launch_bounds__(256) assemble_slots_kernel(const int* __restri
                                                              int max_attempts, int n_rows, int* __restrict__ out_docids,
                                                              float* __restrict__ out_clicks,
                                                              int* __restrict__ out_list_idx, int* __restrict__ info) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  int attempts = 0;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   // A hipGraph replays frozen kernel arguments, so the per-step Philox counter may live in device
   // memory: every block reads it here, and the LAST block to finish bumps it (all reads are done).
   if (step_ctr) step += __hip_atomic_load(step_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (b < B) {
-    int i = 0;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint32_t slot = slot_base + (uint32_t)b;
+    const unsigned long long lmask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+    int i = 0, doc = -1, attempts = 0;
+    float lab = 0.f;
     unsigned long long mask = 0ull;
     for (int a = 0; a < max_attempts; ++a) {
-      PhiloxDraws ph;
-      ph.init(slot_base + (uint32_t)b, (uint32_t)a, step, seed);
-      mask = eval_candidate([&](int d) { return ph.draw(d); }, initial_list, labels, Q, Lmax, L, click_model, t, &i);
+      // draw 0 (words 0,1 of block 0) picks the list: int(random.random() * length) (:132)
+      const Philox4 b0 = philox4x32_10(slot, (uint32_t)a, 0u, step, k0, k1);
+      i = (int)(u53(b0.v[0], b0.v[1]) * (double)Q);
+      i = i < Q ? i : Q - 1;
+      bool c = false;
+      doc = -1;
+      lab = 0.f;
+      if (lane < L) {
+        doc = initial_list[(long long)i * Lmax + lane];
+        lab = doc < 0 ? 0.f : labels[(long long)i * Lmax + lane];  // :80-82
+        if (click_model == ULTR_CLICK_ORACLE) {
+          c = lab != 0.f;
+        } else {
+          const int d = 1 + lane;  // draws 1..L are the click draws (:87)
+          const Philox4 bd = philox4x32_10(slot, (uint32_t)a, (uint32_t)(d >> 1), step, k0, k1);
+          const double u = (d & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+          c = u < click_threshold(t, lane, lab);
+        }
+      }
+      mask = __ballot(c) & lmask;
+      if (click_model == ULTR_CLICK_CASCADE) mask &= (~mask + 1ull);  // only the first click counts
       attempts = a + 1;
       if (!check_validation || mask != 0ull) break;
     }
-    emit_slot(b, i, mask, initial_list, labels, click_model, Lmax, L, B, n_rows, out_docids, out_clicks, out_list_idx);
+    if (lane < L) {
+      out_docids[(long long)lane * B + b] = doc < 0 ? n_rows : doc;  // pad -> the zero row (:140-143)
+      float cv = ((mask >> lane) & 1ull) ? 1.f : 0.f;
+      if (click_model == ULTR_CLICK_ORACLE) cv = lab;
+      out_clicks[(long long)lane * B + b] = cv;
+    }
+    if (lane == 0) {
+      out_list_idx[b] = i;
+      atomicAdd(&info[2], attempts);  // diagnostic: acceptance rate = B / total attempts
+    }
   }
-  // total attempts (diagnostic; acceptance rate = B / total)
-  float v[1] = {(float)attempts};
-  __shared__ float red[8];
-  block_sum<1>(v, red);
-  if (threadIdx.x == 0) atomicAdd(&info[2], (int)v[0]);
   if (step_ctr) {
     if (last_block_arrive(reinterpret_cast<unsigned int*>(&info[3]), gridDim.x) && threadIdx.x == 0)
       __hip_atomic_fetch_add(step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -203,11 +230,17 @@ static int click_common(bool cascade, const float* labels, long long n, int L, c
   ClickTables t{exam, n_exam, click_prob, n_cp};
   const dim3 grid((unsigned)cdiv(n, 256));
   if (cascade)
-    hipLaunchKernelGGL(click_kernel<true>, grid, dim3(256), 0, as_stream(stream), labels, n, L, t, uniforms, seed, step,
+    {
+      ultr::ProfScope prof_("click_kernel", as_stream(stream));
+      hipLaunchKernelGGL(click_kernel<true>, grid, dim3(256), 0, as_stream(stream), labels, n, L, t, uniforms, seed, step,
                        clicks);
+    }
   else
-    hipLaunchKernelGGL(click_kernel<false>, grid, dim3(256), 0, as_stream(stream), labels, n, L, t, uniforms, seed,
+    {
+      ultr::ProfScope prof_("click_kernel", as_stream(stream));
+      hipLaunchKernelGGL(click_kernel<false>, grid, dim3(256), 0, as_stream(stream), labels, n, L, t, uniforms, seed,
                        step, clicks);
+    }
   return check_launch("click_kernel");
 }
 
@@ -246,16 +279,22 @@ extern "C" int ultr_batch_assemble(const int* initial_list, const float* labels,
   ClickTables t{exam, n_exam, click_prob, n_click_prob};
   if (mode == 0) {
     ULTR_REQUIRE(max_attempts >= 1, ULTR_EINVAL, "ultr_batch_assemble: max_attempts=%d", max_attempts);
-    hipLaunchKernelGGL(assemble_slots_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream),
+    {
+      ultr::ProfScope prof_("assemble_slots_kernel", as_stream(stream));
+      hipLaunchKernelGGL(assemble_slots_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream),
                        initial_list, labels, Q, Lmax, L, B, click_model, t, seed, step, step_ctr, slot_base, check_validation,
                        max_attempts, n_rows, out_docids, out_clicks, out_list_idx, info);
+    }
     return check_launch("assemble_slots_kernel");
   }
   ULTR_REQUIRE(mode == 1, ULTR_EINVAL, "ultr_batch_assemble: mode=%d", mode);
   ULTR_REQUIRE(uniforms && n_cand > 0 && slot_start >= 0 && slot_start < B, ULTR_EINVAL,
                "ultr_batch_assemble: sequential mode needs uniforms, n_cand=%d slot_start=%d", n_cand, slot_start);
-  hipLaunchKernelGGL(assemble_sequential_kernel, dim3(1), dim3(1024), 0, as_stream(stream), initial_list, labels, Q,
+  {
+    ultr::ProfScope prof_("assemble_sequential_kernel", as_stream(stream));
+    hipLaunchKernelGGL(assemble_sequential_kernel, dim3(1), dim3(1024), 0, as_stream(stream), initial_list, labels, Q,
                      Lmax, L, B, click_model, t, uniforms, n_cand, slot_start, check_validation, n_rows, out_docids,
                      out_clicks, out_list_idx, info);
+  }
   return check_launch("assemble_sequential_kernel");
 }

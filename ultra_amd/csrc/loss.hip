@@ -20,20 +20,21 @@ __device__ __forceinline__ float sig_ce(float z, float x) { return fmaxf(x, 0.f)
 __device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x); }
 __device__ __forceinline__ float clip_w(float w, float maxw) { return maxw > 0.f ? fminf(fmaxf(w, 0.f), maxw) : w; }
 
-// Per-block accumulation of NS batch sums (or maxima) into LDS, fixed order.
+// Per-block accumulation of batch sums (or maxima), fixed order and barrier-free until combine():
+// add() reduces across the wave with shuffles and parks the result in the wave's LDS row.
 struct BlockStats {
-  float* s_acc;  // [NS]
-  float* s_red;  // [4]
+  float* s_part;  // [4 waves][kMaxStat]
   __device__ __forceinline__ void add(int slot, float v, bool is_max = false) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     v = is_max ? wave_max(v) : wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_part[(threadIdx.x >> 6) * kMaxStat + slot] = v;
+  }
+  __device__ __forceinline__ void combine(float* s_acc, int ns, int max_from) {
     __syncthreads();
-    if (lane == 0) s_red[wid] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float r = s_red[0];
-      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, s_red[w]) : r + s_red[w];
-      s_acc[slot] = r;
+    const int nw = blockDim.x >> 6;
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+      float r = s_part[s];
+      for (int w = 1; w < nw; ++w) r = (s >= max_from) ? fmaxf(r, s_part[w * kMaxStat + s]) : r + s_part[w * kMaxStat + s];
+      s_acc[s] = r;
     }
   }
 };
@@ -73,8 +74,8 @@ __global__ void __launch_bounds__(kLossThreads) ipw_loss_kernel(const float* __r
                                                                 float* __restrict__ stats,
                                                                 float* __restrict__ list_weights, float* ws) {
   __shared__ float s_acc[kMaxStat];
-  __shared__ float s_red[4];
-  BlockStats bs{s_acc, s_red};
+  __shared__ float s_part[4 * kMaxStat];
+  BlockStats bs{s_part};
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = b < B;
   float num = 0.f, den = 0.f, lw = 0.f;
@@ -114,6 +115,7 @@ __global__ void __launch_bounds__(kLossThreads) ipw_loss_kernel(const float* __r
   bs.add(0, num);
   bs.add(1, den);
   for (int l = 0; l < L; ++l) bs.add(2 + l, on ? pw[(long long)l * B + b] : -INFINITY, true);
+  bs.combine(s_acc, 2 + L, 2);
   finish_stats(s_acc, 2 + L, 2, ws, stats);
 }
 
@@ -130,17 +132,31 @@ __global__ void ipw_weights_kernel(const float* __restrict__ clicks, int B, int 
 // stats: [0] rank num [1] rank den [2] exam num [3] exam den [4+l] pw_l [4+L+l] sum_b rw
 // internal partial row adds [4+2L+l] = column sums needed for d exam/d logit
 // ------------------------------------------------------------------------------------------
+template <int LT>  // compile-time bound on L: a list's scores and clicks live in registers
 __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
     const float* __restrict__ scores, const float* __restrict__ clicks, int B, int L,
     const float* __restrict__ prop_params, int loss_func, int prob_kind, float max_pw,
     float* __restrict__ d_scores, float* __restrict__ prop_grads, float* __restrict__ list_weights,
     float* __restrict__ stats, float* ws) {
   __shared__ float s_acc[kMaxStat];
-  __shared__ float s_red[4];
+  __shared__ float s_part[4 * kMaxStat];
   __shared__ float s_logit[ULTR_MAX_LIST], s_pre[ULTR_MAX_LIST], s_prob[ULTR_MAX_LIST], s_pw[ULTR_MAX_LIST],
       s_logp[ULTR_MAX_LIST];
-  BlockStats bs{s_acc, s_red};
+  BlockStats bs{s_part};
   const int tid = threadIdx.x;
+  const int b = blockIdx.x * blockDim.x + tid;
+  const bool on = b < B;
+  // issue every global load of this list up front (independent loads, one round trip)
+  float o[LT], c[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    o[l] = 0.f;
+    c[l] = 0.f;
+    if (l < L && on) {
+      o[l] = scores[(long long)l * B + b];
+      c[l] = clicks[(long long)l * B + b];
+    }
+  }
   // propensity tower: one-hot(position) @ W_0 + b_0 -> ELU  (dla.py:264-304): logit_l = ELU(W[l]+b)
   if (tid < L) {
     const float pre = prop_params[tid] + prop_params[L];
@@ -165,53 +181,51 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
   }
   __syncthreads();
 
-  const int b = blockIdx.x * blockDim.x + tid;
-  const bool on = b < B;
   float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f, lw = 0.f;
-  float m = -INFINITY, mean = 0.f, se = 0.f, S = 0.f, p0 = 1.f;
-  if (on) {
-    for (int l = 0; l < L; ++l) {
-      const float o = scores[(long long)l * B + b];
-      m = fmaxf(m, o);
-      mean += o;
+  float m = -INFINITY, mean = 0.f, se = 0.f, S = 0.f;
+#pragma unroll
+  for (int l = 0; l < LT; ++l)
+    if (l < L) {
+      m = fmaxf(m, o[l]);
+      mean += o[l];
     }
-    mean /= (float)L;
-    for (int l = 0; l < L; ++l) {
-      const long long e = (long long)l * B + b;
-      se += expf(scores[e] - m);
-      S += (clicks[e] + 0.0000001f) * s_pw[l];
+  mean /= (float)L;
+#pragma unroll
+  for (int l = 0; l < LT; ++l)
+    if (l < L) {
+      se += expf(o[l] - m);
+      S += (c[l] + 0.0000001f) * s_pw[l];
     }
-    const float o0 = scores[b];
-    p0 = prob_kind == ULTR_PROB_SOFTMAX ? expf(o0 - m) / se : sigmoidf_(o0 - mean);
-  }
+  const float p0 = prob_kind == ULTR_PROB_SOFTMAX ? expf(o[0] - m) / se : sigmoidf_(o[0] - mean);
   const float lse = m + logf(se);
-  // the L column sums are block reductions, so every thread walks every l
-  for (int l = 0; l < L; ++l) {
-    float rw = 0.f, col = 0.f;
-    if (on) {
-      const long long e = (long long)l * B + b;
-      const float o = scores[e], c = clicks[e];
-      const float pl = prob_kind == ULTR_PROB_SOFTMAX ? expf(o - m) / se : sigmoidf_(o - mean);
-      rw = clip_w(p0 / pl, max_pw);  // relevance weights (dla.py:159-160)
-      lw += s_pw[l] * fminf(fmaxf(c, 0.f), 1.f);
-      if (loss_func == ULTR_LOSS_SOFTMAX) {
-        const float wl = (c + 0.0000001f) * s_pw[l];
-        rank_num -= wl * (o - lse);
-        d_scores[e] = expf(o - lse) * S - wl;
-        const float wle = (c + 0.0000001f) * rw;
-        exam_num -= wle * s_logp[l];
-        exam_den += wle;
-        col = wle;  // d exam/d logit_l = softmax(logit)_l * sum_b S'_b - sum_b wle
-      } else {
-        const float z = fminf(c, 1.f);
-        rank_num += sig_ce(z, o) * s_pw[l];
-        d_scores[e] = (sigmoidf_(o) - z) * s_pw[l];
-        exam_num += sig_ce(z, s_logit[l]) * rw;
-        col = (sigmoidf_(s_logit[l]) - z) * rw;  // d exam/d logit_l directly
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    if (l < L) {  // L is block-uniform: every thread reaches the wave reductions below
+      float rw = 0.f, col = 0.f;
+      if (on) {
+        const long long e = (long long)l * B + b;
+        const float pl = prob_kind == ULTR_PROB_SOFTMAX ? expf(o[l] - m) / se : sigmoidf_(o[l] - mean);
+        rw = clip_w(p0 / pl, max_pw);  // relevance weights (dla.py:159-160)
+        lw += s_pw[l] * fminf(fmaxf(c[l], 0.f), 1.f);
+        if (loss_func == ULTR_LOSS_SOFTMAX) {
+          const float wl = (c[l] + 0.0000001f) * s_pw[l];
+          rank_num -= wl * (o[l] - lse);
+          d_scores[e] = expf(o[l] - lse) * S - wl;
+          const float wle = (c[l] + 0.0000001f) * rw;
+          exam_num -= wle * s_logp[l];
+          exam_den += wle;
+          col = wle;  // d exam/d logit_l = softmax(logit)_l * sum_b S'_b - sum_b wle
+        } else {
+          const float z = fminf(c[l], 1.f);
+          rank_num += sig_ce(z, o[l]) * s_pw[l];
+          d_scores[e] = (sigmoidf_(o[l]) - z) * s_pw[l];
+          exam_num += sig_ce(z, s_logit[l]) * rw;
+          col = (sigmoidf_(s_logit[l]) - z) * rw;  // d exam/d logit_l directly
+        }
       }
+      bs.add(4 + L + l, rw);
+      bs.add(4 + 2 * L + l, col);
     }
-    bs.add(4 + L + l, rw);
-    bs.add(4 + 2 * L + l, col);
   }
   if (on) {
     rank_den = loss_func == ULTR_LOSS_SOFTMAX ? S : 1.f;
@@ -222,8 +236,9 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
   bs.add(1, rank_den);
   bs.add(2, exam_num);
   bs.add(3, exam_den);
+  bs.combine(s_acc, 4 + 3 * L, 1 << 30);
   __syncthreads();
-  if (tid < L) s_acc[4 + tid] = 0.f;  // pw_l is batch independent: filled in by the last block
+  if (tid < L) s_acc[4 + tid] = 0.f;  // pw_l is batch independent: written once by the last block
   if (finish_stats(s_acc, 4 + 3 * L, 1 << 30, ws, stats)) {
     if (tid < L) stats[4 + tid] = s_pw[tid];
     // chain through the tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l
@@ -258,8 +273,8 @@ __global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
     float* __restrict__ d_scores, float* __restrict__ ranker_labels, float* __restrict__ list_weights,
     float* __restrict__ stats, float* d_bias, float* ws) {
   __shared__ float s_acc[kMaxStat];
-  __shared__ float s_red[4];
-  BlockStats bs{s_acc, s_red};
+  __shared__ float s_part[4 * kMaxStat];
+  BlockStats bs{s_part};
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = b < B;
   const float bias = bias_ptr ? bias_ptr[0] : 0.f;
@@ -304,6 +319,7 @@ __global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
   bs.add(0, loss);
   bs.add(1, on ? 1.f : 0.f);
   bs.add(2 + 3 * L, dsum);
+  bs.combine(s_acc, 3 + 3 * L, 1 << 30);
   if (finish_stats(s_acc, 3 + 3 * L, 1 << 30, ws, stats)) {
     if (threadIdx.x == 0 && d_bias) d_bias[0] = s_acc[2 + 3 * L];  // un-normalised d loss / d sigmoid_prob_b
   }
@@ -462,16 +478,22 @@ extern "C" int ultr_loss_ipw_fwdbwd(const float* scores, const float* clicks, co
   ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
                "ultr_loss_ipw_fwdbwd: loss_func=%d (pairwise_loss raises NameError in the reference and is not "
                "supported)", loss_func);
-  hipLaunchKernelGGL(ipw_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
+  {
+    ultr::ProfScope prof_("ipw_loss_kernel", as_stream(stream));
+    hipLaunchKernelGGL(ipw_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
                      scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
+  }
   return check_launch("ipw_loss_kernel");
 }
 
 extern "C" int ultr_ipw_weights(const float* clicks, int B, int L, const float* ipw, int n_ipw, float* pw,
                                 void* stream) {
   ULTR_REQUIRE(clicks && ipw && pw && B > 0 && L > 0 && n_ipw > 0, ULTR_EINVAL, "ultr_ipw_weights: bad argument");
-  hipLaunchKernelGGL(ipw_weights_kernel, dim3((unsigned)cdiv((long long)B * L, 256)), dim3(256), 0, as_stream(stream),
+  {
+    ultr::ProfScope prof_("ipw_weights_kernel", as_stream(stream));
+    hipLaunchKernelGGL(ipw_weights_kernel, dim3((unsigned)cdiv((long long)B * L, 256)), dim3(256), 0, as_stream(stream),
                      clicks, B, L, ipw, n_ipw, pw);
+  }
   return check_launch("ipw_weights_kernel");
 }
 
@@ -485,9 +507,17 @@ extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, in
                "ultr_loss_dla_fwdbwd: loss_func=%d not supported", loss_func);
   ULTR_REQUIRE(logits_to_prob == ULTR_PROB_SOFTMAX || logits_to_prob == ULTR_PROB_SIGMOID, ULTR_EINVAL,
                "ultr_loss_dla_fwdbwd: logits_to_prob=%d", logits_to_prob);
-  hipLaunchKernelGGL(dla_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
-                     scores, clicks, B, L, prop_params, loss_func, logits_to_prob, max_propensity_weight, d_scores,
-                     prop_grads, list_weights, stats, ws);
+  {
+    ultr::ProfScope prof_("dla_loss_kernel", as_stream(stream));
+    if (L <= 16)
+      hipLaunchKernelGGL(dla_loss_kernel<16>, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0,
+                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
+    else
+      hipLaunchKernelGGL(dla_loss_kernel<64>, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0,
+                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
+  }
   return check_launch("dla_loss_kernel");
 }
 
@@ -499,16 +529,22 @@ extern "C" int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, in
   int rc = loss_args_ok("ultr_loss_rem_fwdbwd", scores, clicks, B, L, ws);
   if (rc) return rc;
   ULTR_REQUIRE(propensity && d_scores && stats, ULTR_EINVAL, "ultr_loss_rem_fwdbwd: null pointer");
-  hipLaunchKernelGGL(rem_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
+  {
+    ultr::ProfScope prof_("rem_loss_kernel", as_stream(stream));
+    hipLaunchKernelGGL(rem_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
                      scores, clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base, d_scores,
                      ranker_labels, list_weights, stats, d_bias, ws);
+  }
   return check_launch("rem_loss_kernel");
 }
 
 extern "C" int ultr_rem_update_propensity(float* propensity, int L, const float* stats, float em_step_size,
                                           float* old_out, void* stream) {
   ULTR_REQUIRE(propensity && stats && L > 0 && L <= ULTR_MAX_LIST, ULTR_EINVAL, "ultr_rem_update_propensity: bad args");
-  hipLaunchKernelGGL(rem_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), propensity, L, stats, em_step_size, old_out);
+  {
+    ultr::ProfScope prof_("rem_update_kernel", as_stream(stream));
+    hipLaunchKernelGGL(rem_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), propensity, L, stats, em_step_size, old_out);
+  }
   return check_launch("rem_update_kernel");
 }
 
@@ -522,15 +558,21 @@ extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int
   if (smem > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pd_loss_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(pd_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), smem,
+  {
+    ultr::ProfScope prof_("pd_loss_kernel", as_stream(stream));
+    hipLaunchKernelGGL(pd_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), smem,
                      as_stream(stream), scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws);
+  }
   return check_launch("pd_loss_kernel");
 }
 
 extern "C" int ultr_pd_update_ratios(float* t_plus, float* t_minus, int L, float* stats, float em_step_size,
                                      float regulation_p, float* old_out, void* stream) {
   ULTR_REQUIRE(t_plus && t_minus && stats && L > 0 && L <= kPdMaxL, ULTR_EINVAL, "ultr_pd_update_ratios: bad args");
-  hipLaunchKernelGGL(pd_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), t_plus, t_minus, L, stats,
+  {
+    ultr::ProfScope prof_("pd_update_kernel", as_stream(stream));
+    hipLaunchKernelGGL(pd_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), t_plus, t_minus, L, stats,
                      em_step_size, regulation_p, old_out);
+  }
   return check_launch("pd_update_kernel");
 }

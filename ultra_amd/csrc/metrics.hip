@@ -135,7 +135,87 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
 
   bitonic_sort_tile(t, P, E, Lx, (metric_mask & ULTR_METRIC_NDCG) != 0);
 
-  // one thread per list walks the sorted list
+  if (P <= 64) {
+    // short lists: one lane per (list, rank); a list is a P-lane group inside one wave, so sums, maxima and
+    // the ERR prefix product are shuffles within the group -- no serial walk, every lane busy
+    const int r = tid & (P - 1), li = tid / P, base = li * P;
+    const int b = blockIdx.x * LPB + li;
+    const bool live = r < Lx;
+    const float lb = live ? t.lab[base + t.idx[tid]] : 0.f;
+    const float il = live ? t.ilab[tid] : 0.f;
+    const float gain = live ? exp2f(lb) - 1.f : 0.f, igain = live ? exp2f(il) - 1.f : 0.f;
+    const float disc = logf((float)r + 2.f);
+    const float gd = gain / disc, igd = igain / disc;
+    auto gsum = [&](float v) {
+      for (int o = P >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      return v;
+    };
+    const float rel_sum = gsum(gain);
+    float mrr = (live && lb >= 1.f) ? 1.f / (float)(r + 1) : 0.f;
+    for (int o = P >> 1; o > 0; o >>= 1) mrr = fmaxf(mrr, __shfl_xor(mrr, o, 64));
+    float e_term = 0.f;
+    if (metric_mask & ULTR_METRIC_ERR) {
+      const float rel = gain / powf(2.f, max_label);  // metrics.py:312-313
+      float cum = live ? 1.f - rel : 1.f;             // inclusive prefix product within the group
+      for (int o = 1; o < P; o <<= 1) {
+        const float up = __shfl_up(cum, o, 64);
+        if (r >= o) cum *= up;
+      }
+      e_term = live ? rel * (cum / (1.f - rel)) / (float)(r + 1) : 0.f;  // cumprod/(1-rel) (:314)
+    }
+    float dcg[kMaxTopn], idcg[kMaxTopn], err[kMaxTopn];
+#pragma unroll
+    for (int q = 0; q < kMaxTopn; ++q) {
+      dcg[q] = idcg[q] = err[q] = 0.f;
+      if (q < n_topn) {
+        const bool in = r < topn[q];
+        if (metric_mask & ULTR_METRIC_NDCG) {
+          dcg[q] = gsum(in ? gd : 0.f);
+          idcg[q] = gsum(in ? igd : 0.f);
+        }
+        if (metric_mask & ULTR_METRIC_ERR) err[q] = gsum(in ? e_term : 0.f);
+      }
+    }
+    if (r == 0) {
+      float* vals = s_vals + li * nout;
+      for (int o = 0; o < nout; ++o) vals[o] = 0.f;
+      if (b < B) {
+        const float w = list_weights ? list_weights[b] : 1.f;
+        const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
+        int mi = 0;
+        if (metric_mask & ULTR_METRIC_MRR) {
+#pragma unroll
+          for (int q = 0; q < kMaxTopn; ++q)
+            if (q < n_topn) {
+              vals[(mi * n_topn + q) * 2 + 0] = mrr;
+              vals[(mi * n_topn + q) * 2 + 1] = mrr * w;
+            }
+          ++mi;
+        }
+        if (metric_mask & ULTR_METRIC_NDCG) {
+#pragma unroll
+          for (int q = 0; q < kMaxTopn; ++q)
+            if (q < n_topn) {
+              const float nd = idcg[q] != 0.f ? dcg[q] / idcg[q] : 0.f;
+              const float ndw = (w * idcg[q]) != 0.f ? (w * dcg[q]) / (w * idcg[q]) : 0.f;
+              vals[(mi * n_topn + q) * 2 + 0] = nd * plw_plain;
+              vals[(mi * n_topn + q) * 2 + 1] = ndw * plw_w;
+            }
+          ++mi;
+        }
+        if (metric_mask & ULTR_METRIC_ERR) {
+#pragma unroll
+          for (int q = 0; q < kMaxTopn; ++q)
+            if (q < n_topn) {
+              vals[(mi * n_topn + q) * 2 + 0] = err[q];
+              vals[(mi * n_topn + q) * 2 + 1] = err[q] * w;
+            }
+          ++mi;
+        }
+      }
+    }
+  } else
+  // long lists (evaluation over max_candidate_num): one thread per list walks the sorted list
   if (tid < LPB) {
     const int base = tid * P;
     const int b = blockIdx.x * LPB + tid;
@@ -288,9 +368,12 @@ extern "C" int ultr_metrics(const float* scores, const float* labels, const int*
                         96 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)cdiv(B, LPB)), dim3(kMetThreads), smem, as_stream(stream), scores,
+  {
+    ultr::ProfScope prof_("metrics_kernel", as_stream(stream));
+    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)cdiv(B, LPB)), dim3(kMetThreads), smem, as_stream(stream), scores,
                      labels, docids, n_rows, list_weights, u_pred, B, Lx, P, LPB, n_topn, tn[0], tn[1], tn[2], tn[3],
                      tn[4], tn[5], tn[6], tn[7], metric_mask, max_label, out, ws);
+  }
   return check_launch("metrics_kernel");
 }
 
@@ -305,7 +388,10 @@ extern "C" int ultr_sort_by_scores(const float* scores, const float* u, int B, i
   const size_t smem = sizeof(float) * (size_t)5 * P * LPB;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_perm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                       96 * 1024);
-  hipLaunchKernelGGL(sort_perm_kernel, dim3((unsigned)cdiv(B, LPB)), dim3(kMetThreads), smem, as_stream(stream),
+  {
+    ultr::ProfScope prof_("sort_perm_kernel", as_stream(stream));
+    hipLaunchKernelGGL(sort_perm_kernel, dim3((unsigned)cdiv(B, LPB)), dim3(kMetThreads), smem, as_stream(stream),
                      scores, u, B, Lx, P, LPB, topn, perm);
+  }
   return check_launch("sort_perm_kernel");
 }

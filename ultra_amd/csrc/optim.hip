@@ -49,17 +49,15 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
                                                                     float l2, float clip_norm, float lr, int strategy,
                                                                     int n_partials, float* __restrict__ out_norm,
                                                                     const float* __restrict__ ws) {
-  __shared__ float s_factor;
-  if (threadIdx.x == 0) {
-    float ss = 0.f;
-    for (int p = 0; p < n_partials; ++p) ss += ws[8 + p];  // fixed order: every block gets the same norm
-    const float nrm = sqrtf(ss);
-    if (blockIdx.x == 0 && out_norm) out_norm[0] = nrm;
-    s_factor = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
-  }
-  __syncthreads();
+  __shared__ float red[4];
+  // every block reduces the same partials in the same (fixed) order, so all blocks see one norm
+  float ssq[1] = {0.f};
+  for (int p = threadIdx.x; p < n_partials; p += blockDim.x) ssq[0] += ws[8 + p];
+  block_sum<1>(ssq, red);
+  const float nrm = sqrtf(ssq[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
   const float sc = eff_scale(denom, scale_const);
-  const float f = s_factor;
+  const float f = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
   const long long n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(grads);
   float4* t4 = reinterpret_cast<float4*>(theta);
@@ -138,8 +136,11 @@ extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, l
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
   if (n <= 4096) {
-    hipLaunchKernelGGL(clip_adagrad_small_kernel, dim3(1), dim3(kOptThreads), 0, as_stream(stream), theta, acc, grads,
+    {
+      ultr::ProfScope prof_("clip_adagrad_small_kernel", as_stream(stream));
+      hipLaunchKernelGGL(clip_adagrad_small_kernel, dim3(1), dim3(kOptThreads), 0, as_stream(stream), theta, acc, grads,
                        (int)n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm);
+    }
     return check_launch("clip_adagrad_small_kernel");
   }
   ULTR_REQUIRE(ws, ULTR_EINVAL, "ultr_clip_adagrad: workspace required");
@@ -148,11 +149,17 @@ extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, l
   long long blocks = cdiv(n >> 2, kOptThreads);
   if (blocks > kOptMaxBlocks) blocks = kOptMaxBlocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta,
+  {
+    ultr::ProfScope prof_("gnorm_partial_kernel", as_stream(stream));
+    hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta,
                      grads, n, denom, scale_const, l2, ws);
+  }
   int rc = check_launch("gnorm_partial_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta, acc,
+  {
+    ultr::ProfScope prof_("adagrad_apply_kernel", as_stream(stream));
+    hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta, acc,
                      grads, n, denom, scale_const, l2, clip_norm, lr, strategy, (int)blocks, out_norm, ws);
+  }
   return check_launch("adagrad_apply_kernel");
 }

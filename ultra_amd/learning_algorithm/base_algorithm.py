@@ -234,8 +234,8 @@ class BaseAlgorithm(ABC):
             torch.distributed.all_reduce(tb['bucket'][:tb['n_reduce']])
 
     def _train_metrics(self, tb, batch, scores, weighted):
-        u = None
-        if self.shuffle_ties:
+        u = getattr(self, 'metric_uniforms', None)  # [B, L] tie-break uniforms supplied by the caller (tests)
+        if u is None and self.shuffle_ties:
             u = torch.rand((batch.B, scores.shape[0]), dtype=torch.float32, device=self.device)
         dev_metrics.batch_metrics(self.train_plan, scores, batch.labels, batch.docids, batch.n_rows,
                                   tb['list_weights'] if weighted else None, tb['metrics'], tb['met_ws'], u)

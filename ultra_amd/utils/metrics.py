@@ -101,7 +101,8 @@ def sort_by_scores_indices(scores_bl, uniforms_bl=None, topn=None):
     topn = L if topn is None else min(int(topn), L)
     perm = torch.empty((B, topn), dtype=torch.int32, device=scores_bl.device)
     u = None if uniforms_bl is None else uniforms_bl.contiguous().float()
-    _lib.check(_lib.lib().ultr_sort_by_scores(_lib.ptr(scores_bl.t().contiguous().float()), _lib.ptr(u), int(B),
+    scores_lb = scores_bl.t().contiguous().float()
+    _lib.check(_lib.lib().ultr_sort_by_scores(_lib.ptr(scores_lb), _lib.ptr(u), int(B),
                                               int(L), int(topn), _lib.ptr(perm), _lib.current_stream()),
                'ultr_sort_by_scores')
     return perm
