@@ -41,21 +41,69 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Butterfly reductions at VALU speed: DPP lane permutes inside a 16-lane row (quad_perm, row_half_mirror,
+// row_mirror), then gfx950's v_permlane16_swap / v_permlane32_swap across rows and wave halves.  A
+// ds_bpermute-based __shfl_xor costs an LDS round trip (~100 cycles) per step, and these sums sit on
+// the critical path of kernels that run ONE wave per SIMD.
+typedef unsigned int ultr_u2 __attribute__((ext_vector_type(2)));
+#define ULTR_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float xor16_partner(float v, float* other) {
+  const ultr_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  *other = __uint_as_float(r[1]);
+  return __uint_as_float(r[0]);
+}
+__device__ __forceinline__ float xor32_partner(float v, float* other) {
+  const ultr_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  *other = __uint_as_float(r[1]);
+  return __uint_as_float(r[0]);
+}
+// sum over groups of `width` consecutive lanes (width a power of two <= 64); every lane gets the result
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+  if (WIDTH > 1) v += ULTR_DPP_F(v, 0xB1);   // quad_perm [1,0,3,2]
+  if (WIDTH > 2) v += ULTR_DPP_F(v, 0x4E);   // quad_perm [2,3,0,1]
+  if (WIDTH > 4) v += ULTR_DPP_F(v, 0x141);  // row_half_mirror (quads already uniform)
+  if (WIDTH > 8) v += ULTR_DPP_F(v, 0x140);  // row_mirror
+  if (WIDTH > 16) { float o; const float a = xor16_partner(v, &o); v = a + o; }
+  if (WIDTH > 32) { float o; const float a = xor32_partner(v, &o); v = a + o; }
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+  if (WIDTH > 1) v = fmaxf(v, ULTR_DPP_F(v, 0xB1));
+  if (WIDTH > 2) v = fmaxf(v, ULTR_DPP_F(v, 0x4E));
+  if (WIDTH > 4) v = fmaxf(v, ULTR_DPP_F(v, 0x141));
+  if (WIDTH > 8) v = fmaxf(v, ULTR_DPP_F(v, 0x140));
+  if (WIDTH > 16) { float o; const float a = xor16_partner(v, &o); v = fmaxf(a, o); }
+  if (WIDTH > 32) { float o; const float a = xor32_partner(v, &o); v = fmaxf(a, o); }
   return v;
 }
-// sum over the 32 lanes of one wave half (xor offsets < 32 never cross the halves)
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
+// sum over the 32 lanes of one wave half
+__device__ __forceinline__ float half_sum(float v) { return group_sum<32>(v); }
+// run-time width (power of two <= 64)
+__device__ __forceinline__ float group_sum_rt(float v, int width) {
+  switch (width) {
+    case 1: return v;
+    case 2: return group_sum<2>(v);
+    case 4: return group_sum<4>(v);
+    case 8: return group_sum<8>(v);
+    case 16: return group_sum<16>(v);
+    case 32: return group_sum<32>(v);
+    default: return group_sum<64>(v);
+  }
+}
+__device__ __forceinline__ float group_max_rt(float v, int width) {
+  switch (width) {
+    case 1: return v;
+    case 2: return group_max<2>(v);
+    case 4: return group_max<4>(v);
+    case 8: return group_max<8>(v);
+    case 16: return group_max<16>(v);
+    case 32: return group_max<32>(v);
+    default: return group_max<64>(v);
+  }
 }
 
 // Block-wide sum of NV values per thread; result valid in every thread.  `red` is LDS scratch of

@@ -89,7 +89,7 @@ static Layout make_layout(const UltrDnnDesc* d, long long M) {
     L.gslab[j] = take((long long)L.nsplit[j] * L.K[j] * L.ldn[j]);
     L.sslab[j] = take((long long)L.nsplit[j] * L.ldn[j]);
   }
-  long long rpb = cdiv(M, 512);  // aim for <= 512 partial rows
+  long long rpb = cdiv(M, 64);  // <= 64 partial rows: finalize sums them with 4 row groups per column
   if (rpb < 16) rpb = 16;
   rpb = cdiv(rpb, 4) * 4;
   L.out_rows_per_block = (int)rpb;
@@ -753,15 +753,28 @@ struct FinalizeArgs {
 __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
   __shared__ float red[8];
   const int blk = blockIdx.x;
-  if (blk == p.row_start[p.H]) {  // output layer
+  if (blk >= p.row_start[p.H]) {  // output layer: column sums of the [out_blocks][3K+4] partial rows
+    __shared__ float s_col[4][64];
     const int K = p.Kout, j = p.H;
-    for (int i = threadIdx.x; i < 3 * K + 1; i += blockDim.x) {
-      float s = 0.f;
-      for (int b = 0; b < p.out_blocks; ++b) s += p.outpart[(long long)b * (3 * K + 4) + i];
-      if (i < K) p.grads[p.off_W[j] + i] = s;  // W_out is a plain [K] vector
-      else if (i < 2 * K) { if (p.has_ln) p.grads[p.off_gamma[j] + (i - K)] = s; }
-      else if (i < 3 * K) { if (p.has_ln) p.grads[p.off_beta[j] + (i - 2 * K)] = s; }
-      else p.grads[p.off_b[j]] = s;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = (blk - p.row_start[p.H]) * 64 + c;
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < 3 * K + 1) {
+      int b = g;
+      for (; b + 12 < p.out_blocks; b += 16) {  // 4 independent loads in flight per thread
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] += p.outpart[(long long)(b + 4 * q) * (3 * K + 4) + i];
+      }
+      for (; b < p.out_blocks; b += 4) a4[0] += p.outpart[(long long)b * (3 * K + 4) + i];
+    }
+    s_col[g][c] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    __syncthreads();
+    if (g == 0 && i < 3 * K + 1) {
+      const float sum = (s_col[0][c] + s_col[1][c]) + (s_col[2][c] + s_col[3][c]);
+      if (i < K) p.grads[p.off_W[j] + i] = sum;  // W_out is a plain [K] vector
+      else if (i < 2 * K) { if (p.has_ln) p.grads[p.off_gamma[j] + (i - K)] = sum; }
+      else if (i < 3 * K) { if (p.has_ln) p.grads[p.off_beta[j] + (i - 2 * K)] = sum; }
+      else p.grads[p.off_b[j]] = sum;
     }
     return;
   }
@@ -1027,7 +1040,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
   f.outpart = ws + L.outpart; f.out_blocks = L.out_blocks; f.Kout = L.K[H];
   {
     ultr::ProfScope prof_("finalize_kernel", st);
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(start + 1)), dim3(kThreads), 0, st, f);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(start + (3 * L.K[H] + 1 + 63) / 64)), dim3(kThreads), 0, st, f);
   }
   return check_launch("finalize_kernel");
 }

@@ -261,6 +261,116 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
   }
 }
 
+// DLA for short lists (L <= 16): one lane per (list, rank), a list = 16 consecutive lanes, so the
+// per-list softmaxes are DPP group reductions and each lane evaluates ONE exp instead of L.  At batch
+// 256 this spreads the step's loss over 16 CUs instead of 4 waves on one CU.
+__global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(
+    const float* __restrict__ scores, const float* __restrict__ clicks, int B, int L,
+    const float* __restrict__ prop_params, int loss_func, int prob_kind, float max_pw,
+    float* __restrict__ d_scores, float* __restrict__ prop_grads, float* __restrict__ list_weights,
+    float* __restrict__ stats, float* ws) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  __shared__ float s_tower[4][16];  // pre, logit, logp, pw for the last block's chain rule
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & 15, li = tid >> 4;
+  const int b = blockIdx.x * 16 + li;
+  const bool in_list = r < L, live = in_list && b < B;
+  const long long e = (long long)r * B + (b < B ? b : 0);
+  const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f;
+  // propensity tower (batch independent; every 16-lane group evaluates it): logit_r = ELU(W[r] + b)
+  const float pre = in_list ? prop_params[r] + prop_params[L] : 0.f;
+  const float logit = eluf_(pre);
+  const float tm = group_max<16>(in_list ? logit : -INFINITY);
+  const float te = in_list ? expf(logit - tm) : 0.f;
+  const float tse = group_sum<16>(te);
+  const float logp = logit - tm - logf(tse);
+  const float tmean = group_sum<16>(in_list ? logit : 0.f) / (float)L;
+  const float tprob = prob_kind == ULTR_PROB_SOFTMAX ? te / tse : sigmoidf_(logit - tmean);
+  const float tprob0 = group_sum<16>(r == 0 ? tprob : 0.f);
+  const float pw = in_list ? clip_w(tprob0 / tprob, max_pw) : 0.f;  // dla.py:352-364
+  if (tid < 16) {
+    s_tower[0][tid] = pre;
+    s_tower[1][tid] = logit;
+    s_tower[2][tid] = logp;
+    s_tower[3][tid] = pw;
+  }
+  // the list's own softmax / relevance weights
+  const float m = group_max<16>(live ? o : -INFINITY);
+  const float ex = live ? expf(o - m) : 0.f;
+  const float se = group_sum<16>(ex);
+  const float mean = group_sum<16>(live ? o : 0.f) / (float)L;
+  const float pl = prob_kind == ULTR_PROB_SOFTMAX ? ex / se : sigmoidf_(o - mean);
+  const float p0 = group_sum<16>(r == 0 ? pl : 0.f);
+  const float rw = live ? clip_w(p0 / pl, max_pw) : 0.f;  // relevance weights (dla.py:159-160)
+  const float wl = live ? (c + 0.0000001f) * pw : 0.f;
+  const float S = group_sum<16>(wl);
+  const float lse = m + logf(se);
+  const float cl = fminf(fmaxf(c, 0.f), 1.f);
+  const float lw = group_sum<16>(live ? pw * cl : 0.f);
+  float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f, col = 0.f;
+  if (live) {
+    if (loss_func == ULTR_LOSS_SOFTMAX) {
+      rank_num = -wl * (o - lse);
+      d_scores[e] = expf(o - lse) * S - wl;
+      const float wle = (c + 0.0000001f) * rw;
+      exam_num = -wle * logp;
+      exam_den = wle;
+      col = wle;  // d exam/d logit_l = softmax(logit)_l * sum_b S'_b - sum_b wle
+      rank_den = r == 0 ? S : 0.f;
+    } else {
+      const float z = fminf(c, 1.f);
+      rank_num = sig_ce(z, o) * pw;
+      d_scores[e] = (sigmoidf_(o) - z) * pw;
+      exam_num = sig_ce(z, logit) * rw;
+      col = (sigmoidf_(logit) - z) * rw;  // d exam/d logit_l directly
+      rank_den = r == 0 ? 1.f : 0.f;
+      exam_den = r == 0 ? 1.f : 0.f;
+    }
+    if (r == 0 && list_weights) list_weights[b] = lw / (float)L;
+  }
+  // batch sums: scalars over the whole wave; per-rank columns over the wave's 4 lists (xor 16, xor 32)
+  rank_num = wave_sum(rank_num);
+  rank_den = wave_sum(rank_den);
+  exam_num = wave_sum(exam_num);
+  exam_den = wave_sum(exam_den);
+  float o1, o2;
+  float rws = xor16_partner(rw, &o1);
+  rws += o1;
+  rws = xor32_partner(rws, &o2) + o2;
+  float cols = xor16_partner(col, &o1);
+  cols += o1;
+  cols = xor32_partner(cols, &o2) + o2;
+  float* mine = s_part + wid * kMaxStat;
+  if (lane == 0) {
+    mine[0] = rank_num;
+    mine[1] = rank_den;
+    mine[2] = exam_num;
+    mine[3] = exam_den;
+  }
+  if (lane < L) {
+    mine[4 + lane] = 0.f;  // pw_l is batch independent: written once by the last block
+    mine[4 + L + lane] = rws;
+    mine[4 + 2 * L + lane] = cols;
+  }
+  BlockStats bs{s_part};
+  bs.combine(s_acc, 4 + 3 * L, 1 << 30);
+  if (finish_stats(s_acc, 4 + 3 * L, 1 << 30, ws, stats)) {
+    if (tid < L) stats[4 + tid] = s_tower[3][tid];
+    if (tid == 0) {  // chain through the tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l
+      float db = 0.f;
+      for (int l = 0; l < L; ++l) {
+        const float dlogit = loss_func == ULTR_LOSS_SOFTMAX ? expf(s_tower[2][l]) * s_acc[3] - s_acc[4 + 2 * L + l]
+                                                            : s_acc[4 + 2 * L + l];
+        const float dpre = dlogit * (s_tower[0][l] > 0.f ? 1.f : s_tower[1][l] + 1.f);
+        prop_grads[l] = dpre;
+        db += dpre;
+      }
+      prop_grads[L] = db;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Regression-EM
 // stats: [0] sum loss_b [1] B [2+l] M-step numerator [2+L+l] sum ranker_label [2+2L+l] sum clicks
@@ -456,7 +566,7 @@ __global__ void pd_update_kernel(float* t_plus, float* t_minus, int L, float* st
 using namespace ultr;
 
 extern "C" long long ultr_loss_workspace_floats(int B, int L) {
-  const long long blocks = cdiv(B > 0 ? B : 1, kLossThreads);
+  const long long blocks = cdiv(B > 0 ? B : 1, 16);  // the short-list DLA kernel runs 16 lists per block
   long long ns = 4 + 4 * (long long)L;
   if ((long long)L * L + 1 > ns) ns = (long long)L * L + 1;
   return 8 + blocks * ns;
@@ -510,7 +620,7 @@ extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, in
   {
     ultr::ProfScope prof_("dla_loss_kernel", as_stream(stream));
     if (L <= 16)
-      hipLaunchKernelGGL(dla_loss_kernel<16>, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0,
+      hipLaunchKernelGGL(dla_loss_small_kernel, dim3((unsigned)cdiv(B, 16)), dim3(kLossThreads), 0,
                          as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
                          max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
     else

@@ -146,13 +146,10 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
     const float gain = live ? exp2f(lb) - 1.f : 0.f, igain = live ? exp2f(il) - 1.f : 0.f;
     const float disc = logf((float)r + 2.f);
     const float gd = gain / disc, igd = igain / disc;
-    auto gsum = [&](float v) {
-      for (int o = P >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      return v;
-    };
+    auto gsum = [&](float v) { return group_sum_rt(v, P); };
     const float rel_sum = gsum(gain);
     float mrr = (live && lb >= 1.f) ? 1.f / (float)(r + 1) : 0.f;
-    for (int o = P >> 1; o > 0; o >>= 1) mrr = fmaxf(mrr, __shfl_xor(mrr, o, 64));
+    mrr = group_max_rt(mrr, P);
     float e_term = 0.f;
     if (metric_mask & ULTR_METRIC_ERR) {
       const float rel = gain / powf(2.f, max_label);  // metrics.py:312-313
