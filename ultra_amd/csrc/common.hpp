@@ -127,6 +127,13 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, which makes
+// the compiler drain every outstanding global load (s_waitcnt vmcnt(0)) -- fatal for kernels that keep
+// several chunks of prefetch in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- cross-workgroup "last arriver reduces" hand-off (agent-scope release/acquire) --------
 // Every block stores its partials with plain stores, then calls arrive(); the call returns true
 // in exactly one block (the last to arrive), after which that block may read every block's

@@ -28,6 +28,20 @@ constexpr int BK = 32;        // contraction chunk per LDS stage (16 MFMA steps 
 constexpr int LDK = BK + 4;   // row stride of a k-contiguous LDS tile (conflict-free ds_read_b128)
 constexpr int kThreads = 256; // 4 waves
 
+// Diagnostic build only (-DULTR_STAMPS, tools/kbench.hip): in-kernel phase stamps on the 100 MHz wall clock.
+#ifdef ULTR_STAMPS
+__device__ long long g_stamps[16 * 1024 * 8];
+#define ULTR_STAMP(slot, i)                                                                              \
+  do {                                                                                                   \
+    if (threadIdx.x == 0) {                                                                              \
+      const int b_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                     \
+      if (b_ < 1024) g_stamps[(((slot) * 1024) + b_) * 8 + (i)] = wall_clock64();                        \
+    }                                                                                                    \
+  } while (0)
+#else
+#define ULTR_STAMP(slot, i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // workspace layout (all offsets in floats)
 // ---------------------------------------------------------------------------------------------
@@ -37,7 +51,6 @@ struct Layout {
   int N[ULTR_MAX_LAYERS];              // output width of layer j
   int ldn[ULTR_MAX_LAYERS];            // padded output width (multiple of 4) = row stride of W_j, act_j, dz
   long long act[ULTR_MAX_LAYERS];      // [M][ldn_j]        activations of hidden layer j
-  long long part[ULTR_MAX_LAYERS];     // [M][ntile_j][2]   partial LN stats of act_j
   long long stat[ULTR_MAX_LAYERS + 1]; // [M][2]            (mean, rstd) of layer j's input, j >= 1
   long long dz[2];                     // [M][maxld]        ping-pong gradient buffers
   int nsplit[ULTR_MAX_LAYERS];
@@ -72,7 +85,6 @@ static Layout make_layout(const UltrDnnDesc* d, long long M) {
   for (int j = 0; j < L.H; ++j) {
     if (L.ldn[j] > L.maxld) L.maxld = L.ldn[j];
     L.act[j] = take(M * L.ldn[j]);
-    L.part[j] = take(M * ((L.N[j] + 31) / 32) * 2);
   }
   for (int j = 0; j <= L.H; ++j) L.stat[j] = take(M * 2);
   L.dz[0] = take(M * L.maxld);
@@ -130,21 +142,6 @@ __global__ void __launch_bounds__(kThreads) ln_row_stats_kernel(const float* __r
   }
 }
 
-// merge the per-32-column partials (sum, M2) of one row into (mean, rstd)   [Chan et al.]
-__device__ __forceinline__ float2 merge_partials(const float* __restrict__ part, int N, float eps) {
-  const int ntile = (N + 31) >> 5;
-  float total = 0.f;
-  for (int g = 0; g < ntile; ++g) total += part[2 * g];
-  const float mean = total / (float)N;
-  float m2 = 0.f;
-  for (int g = 0; g < ntile; ++g) {
-    const int cnt = min(32, N - 32 * g);
-    const float d = part[2 * g] / (float)cnt - mean;
-    m2 += part[2 * g + 1] + (float)cnt * d * d;
-  }
-  return make_float2(mean, 1.f / sqrtf(m2 / (float)N + eps));
-}
-
 // ---------------------------------------------------------------------------------------------
 // MFMA micro-kernels.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and
 // B[k = l>>5][j = l&31]; over the 16 steps of a BK=32 chunk, lane half h walks k = 16h + t.
@@ -190,17 +187,73 @@ __device__ __forceinline__ void mma16(const float (&a)[16], const float (&b)[16]
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---------------------------------------------------------------------------------------------
-// forward hidden layer:  act[m][n] = f( LN(x_m) . W[:,n] + b[n] )      tile 32 rows x 128 cols
+// Streaming-B wave GEMM.  At the headline size (M = 2560 rows) a layer is a few hundred 32x32 tiles:
+// far too few to hide latency behind occupancy, so the kernels are built around the length of the
+// dependent chain instead.  What the probes under tools/ showed on MI355X:
+//   * a wait on ANY global load costs a full round trip for everything issued before it (the memory
+//     counter is in-order); L2 answers in ~130 ns, but a "lane owns a row" float4 load visits 32 cache
+//     lines and keeps the CU's L1 busy for as many cycles, so a row-per-lane operand stream saturates L1;
+//   * a workgroup-wide __syncthreads() drains every outstanding load (it fences global memory too).
+// Hence: the A panel (32 rows x the whole contraction, LayerNorm already applied) is brought into LDS
+// ONCE per workgroup with fully coalesced loads (a wave reads whole rows, which also yields the row
+// statistics with two in-wave reductions), and the weights stream from L2 straight into MFMA operand
+// registers as coalesced column reads, three 32-deep chunks ahead of the multiply, with no barrier in
+// the main loop (lds_barrier() orders LDS only).  The contraction is split over the waves of a
+// workgroup (WK) when a layer has fewer than ~1024 tiles; the partial accumulators meet in LDS.
+//   "k-strided" operand: lane (j, h) owns column j and reads 16 rows k = kk .. kk+15 (coalesced over j).
+// Addresses are clamped into the operand, values beyond the contraction length are zero in the panel.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ld_kstrided(const float* __restrict__ colp, int kk, int k_last, int ld,
+                                            float (&f)[16]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) f[t] = colp[(long long)min(kk + t, k_last) * ld];
+}
+__device__ __forceinline__ void zero_tail(float (&f)[16], int kk, int K) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) f[t] = (kk + t < K) ? f[t] : 0.f;
+}
+// Three-stage rotation: LOAD(chunk index, stage) must accept any index (it clamps), COMPUTE(stage, index).
+#define ULTR_STREAM_GEMM(NCH, LOAD, COMPUTE)                    \
+  do {                                                          \
+    int i_ = 0;                                                 \
+    for (; i_ + 3 <= (NCH); i_ += 3) {                          \
+      LOAD(i_ + 2, S2); COMPUTE(S0, i_);                        \
+      LOAD(i_ + 3, S0); COMPUTE(S1, i_ + 1);                    \
+      LOAD(i_ + 4, S1); COMPUTE(S2, i_ + 2);                    \
+    }                                                           \
+    if (i_ < (NCH)) COMPUTE(S0, i_);                            \
+    if (i_ + 1 < (NCH)) COMPUTE(S1, i_ + 1);                    \
+  } while (0)
+
+template <int ACT>
+__device__ __forceinline__ void act16(const f32x16& acc, float bias, bool ok, float (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = ok ? act_fwd(ACT, acc[r] + bias) : 0.f;
+}
+__device__ __forceinline__ void act16_rt(int kind, const f32x16& acc, float bias, bool ok, float (&v)[16]) {
+  switch (kind) {
+    case ULTR_ACT_ELU: act16<ULTR_ACT_ELU>(acc, bias, ok, v); break;
+    case ULTR_ACT_RELU: act16<ULTR_ACT_RELU>(acc, bias, ok, v); break;
+    case ULTR_ACT_SELU: act16<ULTR_ACT_SELU>(acc, bias, ok, v); break;
+    case ULTR_ACT_TANH: act16<ULTR_ACT_TANH>(acc, bias, ok, v); break;
+    default: act16<ULTR_ACT_SIGMOID>(acc, bias, ok, v); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward hidden layer:  act[m][n] = f( LN(x_m) . W[:,n] + b[n] )
+// workgroup = WN x WK waves: 32 rows x (32 WN) columns, contraction split WK ways
+// ---------------------------------------------------------------------------------------------
+constexpr int kPanelMaxK = 1024;  // contraction length held in LDS at a time (hidden widths fit: ULTR_MAX_WIDTH)
+
 struct FwdArgs {
   // input rows: either gathered from the table (layer 0) or dense
   const float* x;          // table [n_rows][ldx]  or  act_{j-1} [M][ldx]
   int ldx;
   const int* docids;       // != NULL: gather rows x[docids[m]] ; docid == n_rows -> zero row
   int n_rows;
-  const float* row_stats;  // gather: table_stats [(n_rows+1)][2] ; dense: unused
-  const float* part_in;    // dense + LN: partial stats of the input [M][ntile_in][2]
-  float* stat_out;         // dense + LN: merged (mean, rstd) [M][2], written by the first column tile
+  const float* row_stats;  // gather: table_stats [(n_rows+1)][2] ; dense: computed here
+  float* stat_out;         // dense + LN: (mean, rstd) of the input rows [M][2], written by the first column tile
   int has_ln;
   float eps;
   const float* gamma; const float* beta; const float* W; const float* bias;
@@ -208,194 +261,298 @@ struct FwdArgs {
   long long M;
   int activation;
   float* act_out;          // [M][ldn]
-  float* part_out;         // [M][ntile_out][2]
-  // fused output layer (only when N <= 128, i.e. one column tile owns complete rows):
+  // fused output layer (FUSE: the workgroup's WN column tiles cover complete rows, N <= 32 WN):
   //   score[m] = LN(act_m) . out_W + out_b ; out_stat[m] = (mean, rstd) of act_m
-  int fuse_out;
   const float* out_gamma; const float* out_beta; const float* out_W; const float* out_bias;
   float* out_stat; float* scores;
 };
 
-__global__ void __launch_bounds__(kThreads) fwd_layer_kernel(FwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[2][32 * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * 128];
-  __shared__ float s_stat[32][2];
-  __shared__ float s_red[32][4][2];
+static inline int panel_stride(int K) { return ((K < kPanelMaxK ? K : kPanelMaxK) + 31) / 32 * 32 + 4; }
+template <int WN, int WK>
+static inline size_t fwd_smem_floats(int K, bool fuse) {
+  return 32 * (size_t)panel_stride(K) + (size_t)(WK - 1) * WN * 1024 + (fuse ? (size_t)WN * 32 * 36 + 32 * 3 * WN : 0);
+}
+
+template <int WN, int WK, bool FUSE, bool GATHER>
+__global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NW = WN * WK;
+  const int PS = ((min(p.K, kPanelMaxK) + 31) & ~31) + 4;  // panel row stride: == 4 (mod 32), conflict-free b128 rows
+  float* s_panel = smem;                             // [32][PS] normalised input rows
+  float* s_acc = smem + 32 * PS;                     // [(WK-1)][WN][16][64] split-K exchange
+  float* s_epi = s_acc + (WK - 1) * WN * 1024;       // FUSE: [WN][32][36] transpose tiles, then [32][WN][3]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int wk = w % WK, wn = w / WK;
   const long long m0 = (long long)blockIdx.x * 32;
-  const int n0 = blockIdx.y * 128;
+  const int n0 = (blockIdx.y * WN + wn) * 32;
+  ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 0);
 
-  // --- row statistics of this block's 32 input rows
-  if (tid < 32) {
-    const long long m = m0 + tid;
-    float2 st = make_float2(0.f, 1.f);
-    if (m < p.M && p.has_ln) {
-      if (p.docids) {
-        const int d = p.docids[m];
-        st = make_float2(p.row_stats[2 * (long long)d], p.row_stats[2 * (long long)d + 1]);
-      } else {
-        st = merge_partials(p.part_in + m * (((p.K + 31) >> 5) * 2), p.K, p.eps);
-        if (blockIdx.y == 0) {
-          p.stat_out[2 * m] = st.x;
-          p.stat_out[2 * m + 1] = st.y;
-        }
-      }
-    }
-    s_stat[tid][0] = st.x;
-    s_stat[tid][1] = st.y;
-  }
-  __syncthreads();
-
-  // --- staging: A 32 rows x 32 k = 256 float4 (one per thread); B 32 k x 128 cols = 1024 float4 (four).
-  // Every global load is UNCONDITIONAL on a clamped (always valid) address and masked afterwards: a load
-  // under a divergent branch makes hipcc wait for it at the end of the branch (vmcnt(0)), which serialises
-  // the whole stage on memory latency.
-  const int a_row = tid >> 3, a_q = tid & 7;
-  const long long a_m = m0 + a_row;
-  bool a_live = a_m < p.M;
-  const float* a_src = p.x;
-  {
-    const long long mc = a_live ? a_m : p.M - 1;
-    if (p.docids) {
-      const int d = p.docids[mc];
-      if (d < p.n_rows) a_src = p.x + (long long)d * p.ldx;
-      else a_live = a_live && p.has_ln;  // pad row: x = 0 (LayerNorm of it is beta, handled by the stats entry)
-      if (d >= p.n_rows) a_src = nullptr;
-    } else {
-      a_src = p.x + mc * p.ldx;
-    }
-  }
-  const bool a_pad = a_src == nullptr;   // zero feature row
-  if (a_pad) a_src = p.x;
-  const float a_mean = s_stat[a_row][0], a_rstd = s_stat[a_row][1];
-  const int k_last4 = ((p.K + 3) & ~3) - 4, x_last4 = p.ldx - 4, n_last4 = p.ldn - 4;
-  struct Regs {
-    float4 a, g, bt, b[4];
-    int ka;
-  } R0, R1;
-  auto load_chunk = [&](int chunk, Regs& r) {
-    const int k0 = chunk * BK;
-    r.ka = k0 + 4 * a_q;
-    r.a = *reinterpret_cast<const float4*>(a_src + min(r.ka, x_last4));
-    if (p.has_ln) {
-      r.g = *reinterpret_cast<const float4*>(p.gamma + min(r.ka, k_last4));
-      r.bt = *reinterpret_cast<const float4*>(p.beta + min(r.ka, k_last4));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      const int row = min(k0 + (f >> 5), p.K - 1), c = min(n0 + 4 * (f & 31), n_last4);
-      r.b[i] = *reinterpret_cast<const float4*>(p.W + (long long)row * p.ldn + c);
-    }
-  };
-  auto store_chunk = [&](Regs& r, int buf) {
-    float4 x = a_pad ? make_float4(0.f, 0.f, 0.f, 0.f) : r.a;
-    if (p.has_ln) {  // LayerNorm applied while staging: (x - mean) * rstd * gamma + beta
-      x.x = (x.x - a_mean) * a_rstd * r.g.x + r.bt.x;
-      x.y = (x.y - a_mean) * a_rstd * r.g.y + r.bt.y;
-      x.z = (x.z - a_mean) * a_rstd * r.g.z + r.bt.z;
-      x.w = (x.w - a_mean) * a_rstd * r.g.w + r.bt.w;
-    }
-    // rows beyond M and k beyond K contribute nothing
-    if (!a_live || r.ka >= p.K) x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r.ka + 1 >= p.K) x.y = 0.f;
-    if (r.ka + 2 >= p.K) x.z = 0.f;
-    if (r.ka + 3 >= p.K) x.w = 0.f;
-    *reinterpret_cast<float4*>(&As[buf][a_row * LDK + 4 * a_q]) = x;
-    const int kb = r.ka - 4 * a_q;  // k0 of the chunk these registers hold
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      float4 v = r.b[i];
-      if (kb + (f >> 5) >= p.K || n0 + 4 * (f & 31) >= p.ldn) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&Bs[buf][(f >> 5) * 128 + 4 * (f & 31)]) = v;
-    }
-  };
+  const int col = n0 + l31;
+  const bool col_ok = col < p.N;
+  const float* bp = p.W + min(col, p.ldn - 1);
+  const int k_last = p.K - 1;
+  struct Frag { float b[16]; } S0, S1, S2;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  auto compute = [&](int buf) {
-    float a[16], b[16];
-    load_frag_kcontig(As[buf], l31, h, a);
-    load_frag_kmajor(Bs[buf], 128, w * 32 + l31, h, b);
-    mma16(a, b, acc);
-  };
-  const int nchunk = (p.K + BK - 1) / BK;
-#define FWD_LOAD(c, R) load_chunk(c, R)
-#define FWD_STORE(R, b) store_chunk(R, b)
-#define FWD_COMPUTE(b) compute(b)
-  ULTR_GEMM_PIPELINE(nchunk, FWD_LOAD, FWD_STORE, FWD_COMPUTE);
+  const float bias = p.bias[min(col, p.N - 1)];
 
-  // --- epilogue: bias + activation + store + partial LayerNorm statistics of the output rows
-  const int col = n0 + w * 32 + l31;
-  const int colbase = n0 + w * 32;
-  const int cnt = min(32, p.N - colbase);
-  const bool col_ok = col < p.N;
-  const float bias = col_ok ? p.bias[col] : 0.f;
-  const int ntile_out = (p.N + 31) >> 5;
-  float v[16];
+  for (int kp0 = 0; kp0 < p.K; kp0 += kPanelMaxK) {  // one pass unless the input is wider than the panel (layer 0 only)
+    const int Kc = min(p.K - kp0, kPanelMaxK);
+    // this wave's share of the pass, in chunks of 32
+    const int nchunk_all = (Kc + 31) >> 5, cps = (nchunk_all + WK - 1) / WK;
+    const int c_begin = wk * cps;
+    const int c_end = min(c_begin + cps, nchunk_all);
+    const int nch = max(c_end - c_begin, 0);
+    const int c_last = max(c_end - 1, 0);
+#define FWD_LOAD(i, S) ld_kstrided(bp, kp0 + 32 * min(c_begin + (i), c_last) + 16 * h, k_last, p.ldn, S.b)
+    FWD_LOAD(0, S0);  // the weight stream starts before the panel is staged
+    FWD_LOAD(1, S1);
+
+    // ---- stage the panel: wave w takes rows w, w + NW, ...; lanes run along k (float4 each, coalesced)
+    if (kp0 > 0) lds_barrier();  // the previous pass has been multiplied out
+    constexpr int RPW = (32 + NW - 1) / NW;            // rows per wave
+    constexpr int QMAX = kPanelMaxK / 256;             // float4 per lane and row
+    const int nq = (Kc + 255) >> 8;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const long long m = m0 + acc_row(r, h);
-    v[r] = col_ok ? act_fwd(p.activation, acc[r] + bias) : 0.f;
-    if (m < p.M && col < p.ldn) p.act_out[m * p.ldn + col] = v[r];
-    float sum = 0.f, m2 = 0.f;
-    if (cnt > 0) {
-      sum = half_sum(v[r]);
-      const float mu = sum / (float)cnt;
-      const float dv = col_ok ? v[r] - mu : 0.f;
-      m2 = half_sum(dv * dv);
-      if (l31 == 0 && m < p.M) {
-        float* dst = p.part_out + (m * ntile_out + (colbase >> 5)) * 2;
-        dst[0] = sum;
-        dst[1] = m2;
+    for (int rr = 0; rr < RPW; rr += 4) {              // four rows at a time: 4 x nq independent loads in flight
+      float4 xv[4][QMAX];
+      float mean[4], rstd[4];
+      bool pad[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = w + (rr + u) * NW;
+        const long long m = min(m0 + row, p.M - 1);
+        const float* src;
+        mean[u] = 0.f; rstd[u] = 1.f; pad[u] = false;
+        if (GATHER) {
+          const int d = p.docids[m];                   // wave-uniform
+          pad[u] = d >= p.n_rows;
+          src = p.x + (long long)(pad[u] ? 0 : d) * p.ldx + kp0;
+          if (p.has_ln) {
+            mean[u] = p.row_stats[2 * (long long)d];
+            rstd[u] = p.row_stats[2 * (long long)d + 1];
+          }
+        } else {
+          src = p.x + m * p.ldx;
+        }
+        const int x_last4 = p.ldx - kp0 - 4;
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q)
+          if (q < nq) xv[u][q] = *reinterpret_cast<const float4*>(src + min(4 * lane + 256 * q, x_last4));
+      }
+      ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 5);
+      if (!GATHER && p.has_ln) {                       // two-pass row statistics, four rows interleaved
+        float sm[4], m2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sm[u] = 0.f;
+#pragma unroll
+          for (int q = 0; q < QMAX; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              sm[u] += (k < Kc ? xv[u][q].x : 0.f) + (k + 1 < Kc ? xv[u][q].y : 0.f) + (k + 2 < Kc ? xv[u][q].z : 0.f) +
+                       (k + 3 < Kc ? xv[u][q].w : 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mean[u] = wave_sum(sm[u]) / (float)Kc;
+        if (mean[0] != 123.f) ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 6);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          m2[u] = 0.f;
+#pragma unroll
+          for (int q = 0; q < QMAX; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              const float d0 = k < Kc ? xv[u][q].x - mean[u] : 0.f, d1 = k + 1 < Kc ? xv[u][q].y - mean[u] : 0.f;
+              const float d2 = k + 2 < Kc ? xv[u][q].z - mean[u] : 0.f, d3 = k + 3 < Kc ? xv[u][q].w - mean[u] : 0.f;
+              m2[u] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          rstd[u] = 1.f / sqrtf(wave_sum(m2[u]) / (float)Kc + p.eps);  // biased variance (keras LayerNormalization)
+          const int row = w + (rr + u) * NW;
+          if (blockIdx.y == 0 && lane == 0 && row < 32 && m0 + row < p.M)
+            *reinterpret_cast<float2*>(p.stat_out + 2 * (m0 + row)) = make_float2(mean[u], rstd[u]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < QMAX; ++q)
+        if (q < nq) {
+          const int k = 4 * lane + 256 * q;
+          float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.has_ln) {
+            const int kc = min(kp0 + k, ((p.K + 3) & ~3) - 4);
+            g = *reinterpret_cast<const float4*>(p.gamma + kc);
+            bt = *reinterpret_cast<const float4*>(p.beta + kc);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int row = w + (rr + u) * NW;
+            if (row < 32 && k < PS - 4) {
+              float4 a;  // (x - mean) * rstd * gamma + beta ; a zero feature row normalises to beta, 0 without LayerNorm
+              const float rs = pad[u] ? 0.f : rstd[u], mu = pad[u] ? 0.f : mean[u];
+              a.x = (xv[u][q].x - mu) * rs * g.x + bt.x;
+              a.y = (xv[u][q].y - mu) * rs * g.y + bt.y;
+              a.z = (xv[u][q].z - mu) * rs * g.z + bt.z;
+              a.w = (xv[u][q].w - mu) * rs * g.w + bt.w;
+              if (k >= Kc) a.x = 0.f;
+              if (k + 1 >= Kc) a.y = 0.f;
+              if (k + 2 >= Kc) a.z = 0.f;
+              if (k + 3 >= Kc) a.w = 0.f;
+              *reinterpret_cast<float4*>(s_panel + row * PS + k) = a;
+            }
+          }
+        }
+    }
+    ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 7);
+    lds_barrier();
+    ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 1);
+
+    auto compute = [&](Frag& S, int i) {
+      const int kk = 32 * (c_begin + i) + 16 * h;
+      float a[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(s_panel + l31 * PS + kk + 4 * q);
+        a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], S.b[t], acc, 0, 0, 0);
+    };
+#define FWD_COMPUTE(S, i) compute(S, i)
+    ULTR_STREAM_GEMM(nch, FWD_LOAD, FWD_COMPUTE);
+  }
+  ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 2);
+
+  // --- split-K: the partial accumulators meet in LDS, slice 0 adds them in slice order
+  if (WK > 1) {
+    if (wk > 0) {
+      float* dst = s_acc + ((size_t)(wk - 1) * WN + wn) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[64 * r] = acc[r];
+    }
+    lds_barrier();
+    if (wk == 0) {
+#pragma unroll
+      for (int s = 1; s < WK; ++s) {
+        const float* src = s_acc + ((size_t)(s - 1) * WN + wn) * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += src[64 * r];
       }
     }
-    if (p.fuse_out && l31 == 0) {
-      s_red[acc_row(r, h)][w][0] = sum;
-      s_red[acc_row(r, h)][w][1] = m2;
-    }
   }
-  if (!p.fuse_out) return;
 
-  // --- fused output layer: this block holds complete rows (N <= 128)
-  __syncthreads();
-  if (tid < 32) {  // merge the (up to 4) column-group partials of each row, Chan's formula as merge_partials
+  // --- epilogue (slice 0): bias + activation in the accumulator layout (one column per lane)
+  float v[16];
+  if (wk == 0) act16_rt(p.activation, acc, bias, col_ok, v);
+  if (!FUSE) {
+    if (wk == 0 && col < p.ldn) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + acc_row(r, h);
+        if (m < p.M) p.act_out[m * p.ldn + col] = v[r];
+      }
+    }
+    ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 3);
+    return;
+  }
+
+  // --- fused output layer: the WN column tiles of this workgroup hold complete rows (N <= 32 WN).  The tile
+  // is turned through LDS so that a lane PAIR owns a row: 16 contiguous columns per lane give float4 stores
+  // and in-lane row sums.
+  float* s_tile = s_epi + wn * (32 * 36);
+  float* s_part = s_epi + WN * 32 * 36;    // [32][WN][2] partial (sum, M2)
+  float* s_sc = s_part + 32 * WN * 2;      // [32][WN]
+  const int cnt = min(32, p.N - n0);
+  const int ntile_out = (p.N + 31) >> 5;
+  if (wk == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_tile[acc_row(r, h) * 36 + l31] = v[r];
+  }
+  lds_barrier();
+  const int e_row = lane >> 1, e_part = lane & 1;
+  const long long e_m = m0 + e_row;
+  const int e_c0 = n0 + 16 * e_part;
+  float x[16];
+  float rsum = 0.f, rm2 = 0.f;
+  float4 og[4], ob[4], ow[4];
+  if (wk == 0) {
+    const int o_last4 = ((p.N + 3) & ~3) - 4;  // output-layer operands of this lane's 16 columns
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = min(e_c0 + 4 * q, o_last4);
+      og[q] = *reinterpret_cast<const float4*>(p.out_gamma + c);
+      ob[q] = *reinterpret_cast<const float4*>(p.out_beta + c);
+      ow[q] = *reinterpret_cast<const float4*>(p.out_W + c);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(s_tile + e_row * 36 + 16 * e_part + 4 * q);
+      x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+    }
+    float s4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s4[q] = (x[4 * q] + x[4 * q + 1]) + (x[4 * q + 2] + x[4 * q + 3]);
+    rsum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    rsum += ULTR_DPP_F(rsum, 0xB1);  // the partner lane holds the other 16 columns
+    const float mu = cnt > 0 ? rsum / (float)cnt : 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float dv = (e_c0 + t < p.N) ? x[t] - mu : 0.f;
+      rm2 += dv * dv;
+    }
+    rm2 += ULTR_DPP_F(rm2, 0xB1);
+    if (cnt > 0 && e_m < p.M) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e_c0 + 4 * q < p.ldn)
+          *reinterpret_cast<float4*>(p.act_out + e_m * p.ldn + e_c0 + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    }
+    if (e_part == 0) *reinterpret_cast<float2*>(s_part + (e_row * WN + wn) * 2) = make_float2(rsum, rm2);
+  }
+  ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 3);
+  lds_barrier();
+  if (wk == 0) {  // every lane merges the column-group partials of its own row (Chan's formula)
     float total = 0.f;
-    for (int g = 0; g < ntile_out; ++g) total += s_red[tid][g][0];
-    const float mean = total / (float)p.N;
+#pragma unroll
+    for (int g = 0; g < WN; ++g) total += g < ntile_out ? s_part[(e_row * WN + g) * 2] : 0.f;
+    const float mu = total / (float)p.N;
     float m2 = 0.f;
-    for (int g = 0; g < ntile_out; ++g) {
+#pragma unroll
+    for (int g = 0; g < WN; ++g) {
       const int c = min(32, p.N - 32 * g);
-      const float d = s_red[tid][g][0] / (float)c - mean;
-      m2 += s_red[tid][g][1] + (float)c * d * d;
+      const float dd = s_part[(e_row * WN + g) * 2] / (float)max(c, 1) - mu;
+      m2 += g < ntile_out ? s_part[(e_row * WN + g) * 2 + 1] + (float)c * dd * dd : 0.f;
     }
     float2 st = make_float2(0.f, 1.f);
-    if (p.has_ln) st = make_float2(mean, 1.f / sqrtf(m2 / (float)p.N + p.eps));
-    s_stat[tid][0] = st.x;
-    s_stat[tid][1] = st.y;
-    if (m0 + tid < p.M && p.has_ln) {
-      p.out_stat[2 * (m0 + tid)] = st.x;
-      p.out_stat[2 * (m0 + tid) + 1] = st.y;
-    }
-  }
-  __syncthreads();
-  const float og = (col_ok && p.has_ln) ? p.out_gamma[col] : 1.f;
-  const float ob = (col_ok && p.has_ln) ? p.out_beta[col] : 0.f;
-  const float ow = col_ok ? p.out_W[col] : 0.f;
+    if (p.has_ln) st = make_float2(mu, 1.f / sqrtf(m2 / (float)p.N + p.eps));
+    if (wn == 0 && e_part == 0 && e_m < p.M && p.has_ln) *reinterpret_cast<float2*>(p.out_stat + 2 * e_m) = st;
+    float dot = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = acc_row(r, h);
-    const float hk = col_ok ? ((v[r] - s_stat[row][0]) * s_stat[row][1] * og + ob) * ow : 0.f;
-    const float part = half_sum(hk);
-    if (l31 == 0) s_red[row][w][0] = part;
+    for (int q = 0; q < 4; ++q) {
+      const float gq[4] = {og[q].x, og[q].y, og[q].z, og[q].w};
+      const float bq[4] = {ob[q].x, ob[q].y, ob[q].z, ob[q].w};
+      const float wq[4] = {ow[q].x, ow[q].y, ow[q].z, ow[q].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xn = (x[4 * q + u] - st.x) * st.y;
+        const float hk = p.has_ln ? xn * gq[u] + bq[u] : x[4 * q + u];
+        dot += (e_c0 + 4 * q + u < p.N) ? hk * wq[u] : 0.f;
+      }
+    }
+    dot += ULTR_DPP_F(dot, 0xB1);
+    if (e_part == 0) s_sc[e_row * WN + wn] = dot;
   }
-  __syncthreads();
-  if (tid < 32 && m0 + tid < p.M) {
+  lds_barrier();
+  if (wk == 0 && wn == 0 && e_part == 0 && e_m < p.M) {
     float sc = p.out_bias[0];
-    for (int g = 0; g < 4; ++g) sc += (g < ntile_out) ? s_red[tid][g][0] : 0.f;
-    p.scores[m0 + tid] = sc;
+    for (int g = 0; g < ntile_out; ++g) sc += s_sc[e_row * WN + g];
+    p.scores[e_m] = sc;
   }
+  ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -403,11 +560,12 @@ __global__ void __launch_bounds__(kThreads) fwd_layer_kernel(FwdArgs p) {
 // ---------------------------------------------------------------------------------------------
 struct OutArgs {
   const float* x; int ldx; const int* docids; int n_rows; const float* row_stats;
-  const float* part_in; float* stat_out; int has_ln; float eps;
+  float* stat_out; int has_ln; float eps;
   const float* gamma; const float* beta; const float* W; const float* bias;
   int K; long long M; float* scores;
 };
 
+// row source + (mean, rstd): layer-0 rows come with precomputed statistics, dense rows are reduced here
 __device__ __forceinline__ float2 out_row_stats(const OutArgs& p, long long m, const float** src) {
   float2 st = make_float2(0.f, 1.f);
   if (p.docids) {
@@ -416,7 +574,18 @@ __device__ __forceinline__ float2 out_row_stats(const OutArgs& p, long long m, c
     if (p.has_ln) st = make_float2(p.row_stats[2 * (long long)d], p.row_stats[2 * (long long)d + 1]);
   } else {
     *src = p.x + m * p.ldx;
-    if (p.has_ln) st = merge_partials(p.part_in + m * (((p.K + 31) >> 5) * 2), p.K, p.eps);
+    if (p.has_ln) {
+      const int lane = threadIdx.x & 63;
+      float sm = 0.f;
+      for (int k = lane; k < p.K; k += 64) sm += (*src)[k];
+      const float mean = wave_sum(sm) / (float)p.K;
+      float m2 = 0.f;
+      for (int k = lane; k < p.K; k += 64) {
+        const float dd = (*src)[k] - mean;
+        m2 += dd * dd;
+      }
+      st = make_float2(mean, 1.f / sqrtf(wave_sum(m2) / (float)p.K + p.eps));
+    }
   }
   return st;
 }
@@ -825,6 +994,57 @@ __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
 
 using namespace ultr;
 
+#ifdef ULTR_STAMPS
+extern "C" int ultr_debug_stamps(long long* host, int n) {
+  if (n > 16 * 1024 * 8) n = 16 * 1024 * 8;
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * (size_t)n);
+  return n;
+}
+#endif
+
+template <int WN, int WK, bool FUSE, bool GATHER>
+static int launch_fwd_g(const FwdArgs& a, hipStream_t st) {
+  const size_t smem = sizeof(float) * fwd_smem_floats<WN, WK>(a.K, FUSE);
+  static bool attr_set = false;  // the panel of a 512-wide layer is already past the 64 KB default
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_layer_kernel<WN, WK, FUSE, GATHER>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("ultr_dnn_forward: cannot raise the dynamic LDS limit");
+      return ULTR_EHIP;
+    }
+    attr_set = true;
+  }
+  ULTR_REQUIRE(smem <= 160 * 1024, ULTR_ELIMIT, "ultr_dnn_forward: layer needs %zu bytes of LDS", smem);
+  {
+    ultr::ProfScope prof_("fwd_layer_kernel", st);
+    hipLaunchKernelGGL((fwd_layer_kernel<WN, WK, FUSE, GATHER>), dim3((unsigned)cdiv(a.M, 32), (unsigned)cdiv(a.N, 32 * WN)),
+                       dim3(64 * WN * WK), smem, st, a);
+  }
+  return check_launch("fwd_layer_kernel");
+}
+template <int WN, int WK, bool FUSE>
+static int launch_fwd(const FwdArgs& a, hipStream_t st) {
+  return a.docids ? launch_fwd_g<WN, WK, FUSE, true>(a, st) : launch_fwd_g<WN, WK, FUSE, false>(a, st);
+}
+// Pick the wave arrangement: about one 32x32 tile per SIMD-slot of the chip (1024 waves), splitting the
+// contraction inside the workgroup when the layer has fewer tiles than that.
+static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st) {
+  const long long tilesM = cdiv(a.M, 32), tilesN = cdiv(a.N, 32);
+  const int chunks = (int)cdiv(a.K < kPanelMaxK ? a.K : kPanelMaxK, 32);
+  if (fuse) {
+    const int WN = tilesN <= 1 ? 1 : tilesN <= 2 ? 2 : 4;
+    const int WK = (tilesM * WN < 1024 && chunks >= 4) ? 2 : 1;
+    if (WN == 1) return WK == 1 ? launch_fwd<1, 1, true>(a, st) : launch_fwd<1, 2, true>(a, st);
+    if (WN == 2) return WK == 1 ? launch_fwd<2, 1, true>(a, st) : launch_fwd<2, 2, true>(a, st);
+    return WK == 1 ? launch_fwd<4, 1, true>(a, st) : launch_fwd<4, 2, true>(a, st);
+  }
+  const long long base = tilesM * tilesN;
+  if (base >= 1024 || chunks < 4) return launch_fwd<4, 1, false>(a, st);
+  if (base * 2 >= 1024 || chunks < 8) return launch_fwd<2, 2, false>(a, st);
+  return launch_fwd<1, 4, false>(a, st);
+}
+
 static int check_desc(const UltrDnnDesc* d, const char* who) {
   ULTR_REQUIRE(d, ULTR_EINVAL, "%s: null descriptor", who);
   ULTR_REQUIRE(d->n_layers >= 1 && d->n_layers <= ULTR_MAX_LAYERS, ULTR_ELIMIT, "%s: n_layers=%d not in [1,%d]", who,
@@ -897,25 +1117,20 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
       a.x = table; a.ldx = ldx; a.docids = docids; a.n_rows = n_rows; a.row_stats = table_stats;
     } else {
       a.x = ws + L.act[j - 1]; a.ldx = L.ldn[j - 1]; a.docids = nullptr; a.n_rows = 0;
-      a.part_in = ws + L.part[j - 1]; a.stat_out = ws + L.stat[j];
+      a.stat_out = ws + L.stat[j];
     }
     a.has_ln = has_ln; a.eps = desc->ln_eps;
     a.gamma = params + desc->off_gamma[j]; a.beta = params + desc->off_beta[j];
     a.W = params + desc->off_W[j]; a.bias = params + desc->off_b[j];
     a.K = L.K[j]; a.N = L.N[j]; a.ldn = L.ldn[j]; a.M = M; a.activation = desc->activation;
-    a.act_out = ws + L.act[j]; a.part_out = ws + L.part[j];
-    if (j == L.H - 1 && L.N[j] <= 128) {  // the last hidden layer also produces the scores
-      a.fuse_out = 1;
+    a.act_out = ws + L.act[j];
+    const bool fuse = j == L.H - 1 && L.N[j] <= 128;  // the last hidden layer also produces the scores
+    if (fuse) {
       a.out_gamma = params + desc->off_gamma[L.H]; a.out_beta = params + desc->off_beta[L.H];
       a.out_W = params + desc->off_W[L.H]; a.out_bias = params + desc->off_b[L.H];
       a.out_stat = ws + L.stat[L.H]; a.scores = scores;
     }
-    {
-      ultr::ProfScope prof_("fwd_layer_kernel", st);
-      hipLaunchKernelGGL(fwd_layer_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.N[j], 128)), dim3(kThreads), 0,
-                       st, a);
-    }
-    rc = check_launch("fwd_layer_kernel");
+    rc = launch_fwd_layer(a, fuse, st);
     if (rc) return rc;
   }
   if (L.H > 0 && L.N[L.H - 1] <= 128) return ULTR_OK;  // scores came out of the fused epilogue
@@ -924,7 +1139,7 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
   if (j == 0) {
     o.x = table; o.ldx = ldx; o.docids = docids; o.n_rows = n_rows; o.row_stats = table_stats;
   } else {
-    o.x = ws + L.act[j - 1]; o.ldx = L.ldn[j - 1]; o.part_in = ws + L.part[j - 1]; o.stat_out = ws + L.stat[j];
+    o.x = ws + L.act[j - 1]; o.ldx = L.ldn[j - 1]; o.stat_out = ws + L.stat[j];
   }
   o.has_ln = has_ln; o.eps = desc->ln_eps;
   o.gamma = params + desc->off_gamma[j]; o.beta = params + desc->off_beta[j];
