@@ -191,11 +191,16 @@ __host__ __device__ __forceinline__ float u24(uint32_t a) { return (float)(a >> 
 #define ULTR_SELU_ALPHA 1.6732632423543772848170429916717f
 #define ULTR_SELU_SCALE 1.0507009873554804934193349852946f
 
+// exp(z) - 1 for z <= 0 through the hardware exponential: 3 instructions instead of libm's ~45.  The
+// absolute error is one ulp of exp(z) <= 6e-8, which is what matters downstream (the activations are O(1)
+// and the derivative is taken from the output, a + 1 = exp(z)); the kernels run one wave per SIMD, where
+// every instruction of the epilogue is on the critical path.
+__device__ __forceinline__ float expm1_neg(float z) { return __expf(z) - 1.f; }
 __device__ __forceinline__ float act_fwd(int kind, float z) {
   switch (kind) {
-    case ULTR_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case ULTR_ACT_ELU: return z > 0.f ? z : expm1_neg(z);
     case ULTR_ACT_RELU: return fmaxf(z, 0.f);
-    case ULTR_ACT_SELU: return ULTR_SELU_SCALE * (z >= 0.f ? z : ULTR_SELU_ALPHA * expm1f(z));
+    case ULTR_ACT_SELU: return ULTR_SELU_SCALE * (z >= 0.f ? z : ULTR_SELU_ALPHA * expm1_neg(z));
     case ULTR_ACT_TANH: return tanhf(z);
     default: return 1.f / (1.f + expf(-z));
   }

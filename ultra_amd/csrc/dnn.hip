@@ -203,10 +203,19 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 //   "k-strided" operand: lane (j, h) owns column j and reads 16 rows k = kk .. kk+15 (coalesced over j).
 // Addresses are clamped into the operand, values beyond the contraction length are zero in the panel.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ld_kstrided(const float* __restrict__ colp, int kk, int k_last, int ld,
+// full chunk: element index of row k = kk0 + 16h + t is (kk0 + t) * ld + (16h * ld + col): a wave-uniform
+// term (scalar registers) plus one per-lane 32-bit offset, i.e. one vector add per load.
+__device__ __forceinline__ void ld_kstrided(const float* __restrict__ W, int ld, int kk0, unsigned lane_off,
                                             float (&f)[16]) {
+  const unsigned base = (unsigned)kk0 * (unsigned)ld + lane_off;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) f[t] = colp[(long long)min(kk + t, k_last) * ld];
+  for (int t = 0; t < 16; ++t) f[t] = W[base + (unsigned)t * (unsigned)ld];
+}
+// tail chunk (kk0 + 32 > K): row indices clamped to the last valid row (the panel holds zeros there)
+__device__ __forceinline__ void ld_kstrided_tail(const float* __restrict__ W, int ld, int kk0, int h, int colc, int k_last,
+                                                 float (&f)[16]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) f[t] = W[(size_t)min(kk0 + 16 * h + t, k_last) * ld + colc];
 }
 __device__ __forceinline__ void zero_tail(float (&f)[16], int kk, int K) {
 #pragma unroll
@@ -270,17 +279,18 @@ struct FwdArgs {
 static inline int panel_stride(int K) { return ((K < kPanelMaxK ? K : kPanelMaxK) + 31) / 32 * 32 + 4; }
 template <int WN, int WK>
 static inline size_t fwd_smem_floats(int K, bool fuse) {
-  return 32 * (size_t)panel_stride(K) + (size_t)(WK - 1) * WN * 1024 + (fuse ? (size_t)WN * 32 * 36 + 32 * 3 * WN : 0);
+  const size_t panel = 32 * (size_t)panel_stride(K), exch = (size_t)(WK > 1 ? WK : 0) * WN * 1024;
+  return (panel > exch ? panel : exch) + (fuse ? (size_t)WN * 32 * 36 + 32 * 3 * WN : 0);
 }
 
 template <int WN, int WK, bool FUSE, bool GATHER>
-__global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
+__global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NW = WN * WK;
   const int PS = ((min(p.K, kPanelMaxK) + 31) & ~31) + 4;  // panel row stride: == 4 (mod 32), conflict-free b128 rows
   float* s_panel = smem;                             // [32][PS] normalised input rows
-  float* s_acc = smem + 32 * PS;                     // [(WK-1)][WN][16][64] split-K exchange
-  float* s_epi = s_acc + (WK - 1) * WN * 1024;       // FUSE: [WN][32][36] transpose tiles, then [32][WN][3]
+  float* s_acc = smem;                               // [WK][WN][16][64] split-K exchange, reuses the panel (WK > 1)
+  float* s_epi = smem + max(32 * PS, (WK > 1 ? WK : 0) * WN * 1024);       // FUSE: [WN][32][36] transpose tiles, then [32][WN][3]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int wk = w % WK, wn = w / WK;
   const long long m0 = (long long)blockIdx.x * 32;
@@ -289,7 +299,8 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
 
   const int col = n0 + l31;
   const bool col_ok = col < p.N;
-  const float* bp = p.W + min(col, p.ldn - 1);
+  const int colc = min(col, p.ldn - 1);
+  const unsigned lane_off = (unsigned)(16 * h * p.ldn + colc);
   const int k_last = p.K - 1;
   struct Frag { float b[16]; } S0, S1, S2;
   f32x16 acc;
@@ -305,7 +316,12 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
     const int c_end = min(c_begin + cps, nchunk_all);
     const int nch = max(c_end - c_begin, 0);
     const int c_last = max(c_end - 1, 0);
-#define FWD_LOAD(i, S) ld_kstrided(bp, kp0 + 32 * min(c_begin + (i), c_last) + 16 * h, k_last, p.ldn, S.b)
+#define FWD_LOAD(i, S)                                                                        \
+  do {                                                                                       \
+    const int kk0_ = kp0 + 32 * min(c_begin + (i), c_last);                                  \
+    if (kk0_ + 32 <= p.K) ld_kstrided(p.W, p.ldn, kk0_, lane_off, S.b);                      \
+    else ld_kstrided_tail(p.W, p.ldn, kk0_, h, colc, k_last, S.b);                           \
+  } while (0)
     FWD_LOAD(0, S0);  // the weight stream starts before the panel is staged
     FWD_LOAD(1, S1);
 
@@ -314,6 +330,17 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
     constexpr int RPW = (32 + NW - 1) / NW;            // rows per wave
     constexpr int QMAX = kPanelMaxK / 256;             // float4 per lane and row
     const int nq = (Kc + 255) >> 8;
+    float4 gq[QMAX], bq[QMAX];                         // gamma / beta of this lane's columns, in flight with the rows
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+      gq[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+      bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < nq && p.has_ln) {
+        const int kc = min(kp0 + 4 * lane + 256 * q, ((p.K + 3) & ~3) - 4);
+        gq[q] = *reinterpret_cast<const float4*>(p.gamma + kc);
+        bq[q] = *reinterpret_cast<const float4*>(p.beta + kc);
+      }
+    }
 #pragma unroll
     for (int rr = 0; rr < RPW; rr += 4) {              // four rows at a time: 4 x nq independent loads in flight
       float4 xv[4][QMAX];
@@ -341,7 +368,6 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
         for (int q = 0; q < QMAX; ++q)
           if (q < nq) xv[u][q] = *reinterpret_cast<const float4*>(src + min(4 * lane + 256 * q, x_last4));
       }
-      ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 5);
       if (!GATHER && p.has_ln) {                       // two-pass row statistics, four rows interleaved
         float sm[4], m2[4];
 #pragma unroll
@@ -357,7 +383,6 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) mean[u] = wave_sum(sm[u]) / (float)Kc;
-        if (mean[0] != 123.f) ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 6);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           m2[u] = 0.f;
@@ -382,12 +407,7 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
       for (int q = 0; q < QMAX; ++q)
         if (q < nq) {
           const int k = 4 * lane + 256 * q;
-          float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.has_ln) {
-            const int kc = min(kp0 + k, ((p.K + 3) & ~3) - 4);
-            g = *reinterpret_cast<const float4*>(p.gamma + kc);
-            bt = *reinterpret_cast<const float4*>(p.beta + kc);
-          }
+          const float4 g = gq[q], bt = bq[q];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int row = w + (rr + u) * NW;
@@ -407,7 +427,6 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
           }
         }
     }
-    ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 7);
     lds_barrier();
     ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 1);
 
@@ -427,33 +446,44 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
   }
   ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 2);
 
-  // --- split-K: the partial accumulators meet in LDS, slice 0 adds them in slice order
+  // --- split-K: every slice parks its accumulator in LDS; slice wk then owns registers [wk R, (wk+1) R) of the
+  // tile (R = 16 / WK), adds them over the slices in slice order, and carries them through the epilogue, so
+  // all waves of the workgroup share the activation math and the stores.
+  constexpr int R = 16 / WK;
+  float v[R];
   if (WK > 1) {
-    if (wk > 0) {
-      float* dst = s_acc + ((size_t)(wk - 1) * WN + wn) * 1024 + lane;
+    lds_barrier();  // every wave is done with the panel: the exchange buffer takes its place
+    float* dst = s_acc + ((size_t)wk * WN + wn) * 1024 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[64 * r] = acc[r];
-    }
+    for (int r = 0; r < 16; ++r) dst[64 * r] = acc[r];
     lds_barrier();
-    if (wk == 0) {
 #pragma unroll
-      for (int s = 1; s < WK; ++s) {
-        const float* src = s_acc + ((size_t)(s - 1) * WN + wn) * 1024 + lane;
+    for (int i = 0; i < R; ++i) {
+      float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += src[64 * r];
-      }
+      for (int sl = 0; sl < WK; ++sl) sum += s_acc[((size_t)sl * WN + wn) * 1024 + 64 * (wk * R + i) + lane];
+      v[i] = sum;
     }
-  }
-
-  // --- epilogue (slice 0): bias + activation in the accumulator layout (one column per lane)
-  float v[16];
-  if (wk == 0) act16_rt(p.activation, acc, bias, col_ok, v);
-  if (!FUSE) {
-    if (wk == 0 && col < p.ldn) {
+  } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + acc_row(r, h);
-        if (m < p.M) p.act_out[m * p.ldn + col] = v[r];
+    for (int i = 0; i < R; ++i) v[i] = acc[i];
+  }
+  // --- epilogue: bias + activation in the accumulator layout (one column per lane)
+  switch (p.activation) {
+#define ULTR_ACT_CASE(A) case A: _Pragma("unroll") for (int i = 0; i < R; ++i) v[i] = col_ok ? act_fwd(A, v[i] + bias) : 0.f; break;
+    ULTR_ACT_CASE(ULTR_ACT_ELU)
+    ULTR_ACT_CASE(ULTR_ACT_RELU)
+    ULTR_ACT_CASE(ULTR_ACT_SELU)
+    ULTR_ACT_CASE(ULTR_ACT_TANH)
+    default: _Pragma("unroll") for (int i = 0; i < R; ++i) v[i] = col_ok ? act_fwd(ULTR_ACT_SIGMOID, v[i] + bias) : 0.f; break;
+#undef ULTR_ACT_CASE
+  }
+  if (!FUSE) {
+    if (col < p.ldn) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const long long m = m0 + acc_row(wk * R + i, h);
+        if (m < p.M) p.act_out[m * p.ldn + col] = v[i];
       }
     }
     ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 3);
@@ -468,10 +498,8 @@ __global__ void __launch_bounds__(64 * WN * WK) fwd_layer_kernel(FwdArgs p) {
   float* s_sc = s_part + 32 * WN * 2;      // [32][WN]
   const int cnt = min(32, p.N - n0);
   const int ntile_out = (p.N + 31) >> 5;
-  if (wk == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_tile[acc_row(r, h) * 36 + l31] = v[r];
-  }
+  for (int i = 0; i < R; ++i) s_tile[acc_row(wk * R + i, h) * 36 + l31] = v[i];
   lds_barrier();
   const int e_row = lane >> 1, e_part = lane & 1;
   const long long e_m = m0 + e_row;
