@@ -19,6 +19,7 @@
 //    layer 0 needs no dgrad GEMM at all), dgrad dh = dz W^T, then a row pass applies the
 //    LayerNorm backward and the activation derivative (from the stored activation output).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace ultr {
 
@@ -52,7 +53,8 @@ struct Layout {
   int ldn[ULTR_MAX_LAYERS];            // padded output width (multiple of 4) = row stride of W_j, act_j, dz
   long long act[ULTR_MAX_LAYERS];      // [M][ldn_j]        activations of hidden layer j
   long long stat[ULTR_MAX_LAYERS + 1]; // [M][2]            (mean, rstd) of layer j's input, j >= 1
-  long long dz[2];                     // [M][maxld]        ping-pong gradient buffers
+  long long dz[3];                     // [M][maxld]        rotating gradient buffers
+  long long xhat[ULTR_MAX_LAYERS];     // [M][round4(K_j)]  normalised input rows of layer j (for wgrad)
   int nsplit[ULTR_MAX_LAYERS];
   int rows_per_split[ULTR_MAX_LAYERS];
   long long gslab[ULTR_MAX_LAYERS];    // [nsplit][K_j][ldn_j]
@@ -87,8 +89,10 @@ static Layout make_layout(const UltrDnnDesc* d, long long M) {
     L.act[j] = take(M * L.ldn[j]);
   }
   for (int j = 0; j <= L.H; ++j) L.stat[j] = take(M * 2);
-  L.dz[0] = take(M * L.maxld);
-  L.dz[1] = take(M * L.maxld);
+  for (int i = 0; i < 3; ++i) L.dz[i] = take(M * L.maxld);
+  for (int j = 0; j < L.H; ++j) {
+    L.xhat[j] = take(M * round4(L.K[j]));
+  }
   for (int j = 0; j < L.H; ++j) {
     const long long tiles = cdiv(L.K[j], 64) * cdiv(L.N[j], 64);
     long long want = cdiv(256, tiles);  // ~one workgroup per CU per layer
@@ -101,9 +105,8 @@ static Layout make_layout(const UltrDnnDesc* d, long long M) {
     L.gslab[j] = take((long long)L.nsplit[j] * L.K[j] * L.ldn[j]);
     L.sslab[j] = take((long long)L.nsplit[j] * L.ldn[j]);
   }
-  long long rpb = cdiv(M, 64);  // <= 64 partial rows: finalize sums them with 4 row groups per column
+  long long rpb = cdiv(cdiv(M, 256), 16) * 16;  // 16 rows = one batch of four rows for each of the four waves
   if (rpb < 16) rpb = 16;
-  rpb = cdiv(rpb, 4) * 4;
   L.out_rows_per_block = (int)rpb;
   L.out_blocks = (int)cdiv(M, rpb);
   L.outpart = take((long long)L.out_blocks * (3 * L.K[L.H] + 4));
@@ -253,6 +256,7 @@ __device__ __forceinline__ void act16_rt(int kind, const f32x16& acc, float bias
 // forward hidden layer:  act[m][n] = f( LN(x_m) . W[:,n] + b[n] )
 // workgroup = WN x WK waves: 32 rows x (32 WN) columns, contraction split WK ways
 // ---------------------------------------------------------------------------------------------
+constexpr int kActNone = -1;
 constexpr int kPanelMaxK = 1024;  // contraction length held in LDS at a time (hidden widths fit: ULTR_MAX_WIDTH)
 
 struct FwdArgs {
@@ -268,8 +272,10 @@ struct FwdArgs {
   const float* gamma; const float* beta; const float* W; const float* bias;
   int K, N, ldn;
   long long M;
-  int activation;
+  int activation;          // ULTR_ACT_* or kActNone (plain GEMM)
   float* act_out;          // [M][ldn]
+  float* xhat_out;         // != NULL: normalised input rows (x - mean) * rstd [M][ldxh], kept for wgrad
+  int ldxh;
   // fused output layer (FUSE: the workgroup's WN column tiles cover complete rows, N <= 32 WN):
   //   score[m] = LN(act_m) . out_W + out_b ; out_stat[m] = (mean, rstd) of act_m
   const float* out_gamma; const float* out_beta; const float* out_W; const float* out_bias;
@@ -283,7 +289,7 @@ static inline size_t fwd_smem_floats(int K, bool fuse) {
   return (panel > exch ? panel : exch) + (fuse ? (size_t)WN * 32 * 36 + 32 * 3 * WN : 0);
 }
 
-template <int WN, int WK, bool FUSE, bool GATHER>
+template <int WN, int WK, bool FUSE, bool GATHER, int QMAX>
 __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NW = WN * WK;
@@ -306,7 +312,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float bias = p.bias[min(col, p.N - 1)];
+  const float bias = p.bias ? p.bias[min(col, p.N - 1)] : 0.f;
 
   for (int kp0 = 0; kp0 < p.K; kp0 += kPanelMaxK) {  // one pass unless the input is wider than the panel (layer 0 only)
     const int Kc = min(p.K - kp0, kPanelMaxK);
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
     // ---- stage the panel: wave w takes rows w, w + NW, ...; lanes run along k (float4 each, coalesced)
     if (kp0 > 0) lds_barrier();  // the previous pass has been multiplied out
     constexpr int RPW = (32 + NW - 1) / NW;            // rows per wave
-    constexpr int QMAX = kPanelMaxK / 256;             // float4 per lane and row
+    // QMAX (template): float4 per lane and row the staging registers are sized for, 256 * QMAX >= min(K, panel)
     const int nq = (Kc + 255) >> 8;
     float4 gq[QMAX], bq[QMAX];                         // gamma / beta of this lane's columns, in flight with the rows
 #pragma unroll
@@ -412,17 +418,19 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
           for (int u = 0; u < 4; ++u) {
             const int row = w + (rr + u) * NW;
             if (row < 32 && k < PS - 4) {
-              float4 a;  // (x - mean) * rstd * gamma + beta ; a zero feature row normalises to beta, 0 without LayerNorm
+              float4 a, xh;  // (x - mean) * rstd * gamma + beta ; a zero feature row normalises to beta, 0 without LayerNorm
               const float rs = pad[u] ? 0.f : rstd[u], mu = pad[u] ? 0.f : mean[u];
-              a.x = (xv[u][q].x - mu) * rs * g.x + bt.x;
-              a.y = (xv[u][q].y - mu) * rs * g.y + bt.y;
-              a.z = (xv[u][q].z - mu) * rs * g.z + bt.z;
-              a.w = (xv[u][q].w - mu) * rs * g.w + bt.w;
-              if (k >= Kc) a.x = 0.f;
-              if (k + 1 >= Kc) a.y = 0.f;
-              if (k + 2 >= Kc) a.z = 0.f;
-              if (k + 3 >= Kc) a.w = 0.f;
+              xh.x = k < Kc ? (xv[u][q].x - mu) * rs : 0.f;
+              xh.y = k + 1 < Kc ? (xv[u][q].y - mu) * rs : 0.f;
+              xh.z = k + 2 < Kc ? (xv[u][q].z - mu) * rs : 0.f;
+              xh.w = k + 3 < Kc ? (xv[u][q].w - mu) * rs : 0.f;
+              a.x = k < Kc ? xh.x * g.x + bt.x : 0.f;
+              a.y = k + 1 < Kc ? xh.y * g.y + bt.y : 0.f;
+              a.z = k + 2 < Kc ? xh.z * g.z + bt.z : 0.f;
+              a.w = k + 3 < Kc ? xh.w * g.w + bt.w : 0.f;
               *reinterpret_cast<float4*>(s_panel + row * PS + k) = a;
+              if (p.xhat_out && blockIdx.y == 0 && m0 + row < p.M && kp0 + k < p.ldxh)
+                *reinterpret_cast<float4*>(p.xhat_out + (m0 + row) * p.ldxh + kp0 + k) = xh;
             }
           }
         }
@@ -470,6 +478,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
   }
   // --- epilogue: bias + activation in the accumulator layout (one column per lane)
   switch (p.activation) {
+    case kActNone: _Pragma("unroll") for (int i = 0; i < R; ++i) v[i] = col_ok ? v[i] + bias : 0.f; break;
 #define ULTR_ACT_CASE(A) case A: _Pragma("unroll") for (int i = 0; i < R; ++i) v[i] = col_ok ? act_fwd(A, v[i] + bias) : 0.f; break;
     ULTR_ACT_CASE(ULTR_ACT_ELU)
     ULTR_ACT_CASE(ULTR_ACT_RELU)
@@ -650,10 +659,14 @@ struct BwdOutArgs {
   float* dz; int lddz;     // [M][lddz]
   int rows_per_block;
   float* partials;         // [gridDim.x][3K+4]: dW[K], dgamma[K], dbeta[K], db
+  float* zero; long long zero_n4;  // the flat gradient buffer, cleared here (float4 units) instead of by a memset node
 };
 
-__global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
+// generic fallback for very wide inputs (no hidden layer and more than 1024 features): LDS accumulators
+__global__ void __launch_bounds__(kThreads) bwd_out_wide_kernel(BwdOutArgs p) {
   extern __shared__ float smem[];  // [4 waves][3K+1]
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < p.zero_n4; i += (long long)gridDim.x * kThreads)
+    reinterpret_cast<float4*>(p.zero)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int K = p.f.K;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* acc = smem + w * (3 * K + 1);
@@ -718,14 +731,143 @@ __global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
   }
 }
 
+// One wave per row, four rows in flight per wave (all their loads are issued before the first use); lane l
+// owns columns k = l + 64 q and keeps the parameter-gradient sums of its columns in registers across the
+// wave's rows.  The four waves of a workgroup meet in LDS and write one partial row; finalize adds the rows.
+template <int KQ>
+__global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
+  extern __shared__ float smem[];  // [4 waves][3K+1]
+  const int K = p.f.K;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < p.zero_n4; i += (long long)gridDim.x * kThreads)
+    reinterpret_cast<float4*>(p.zero)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float wv[KQ], gv[KQ], bv[KQ], aW[KQ], aG[KQ], aB[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = lane + 64 * q, kc = min(k, K - 1);
+    const bool ok = k < K;
+    wv[q] = ok ? p.f.W[kc] : 0.f;
+    gv[q] = (ok && p.f.has_ln) ? p.f.gamma[kc] : (ok ? 1.f : 0.f);
+    bv[q] = (ok && p.f.has_ln) ? p.f.beta[kc] : 0.f;
+    aW[q] = aG[q] = aB[q] = 0.f;
+  }
+  float db = 0.f;
+  const long long m_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long m_end = m_begin + p.rows_per_block;
+  if (m_end > p.f.M) m_end = p.f.M;
+  const float inv_k = 1.f / (float)K;
+  for (long long mb = m_begin + w; mb < m_end; mb += 16) {  // rows mb, mb + 4, mb + 8, mb + 12
+    float x[4][KQ], go[4], mean[4], rstd[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long m = mb + 4 * u;
+      live[u] = m < m_end;
+      const long long mc = live[u] ? m : m_end - 1;
+      go[u] = p.d_scores[mc];
+      const float* src;
+      mean[u] = 0.f; rstd[u] = 1.f;
+      bool pad = false;
+      if (p.f.docids) {
+        const int d = p.f.docids[mc];
+        pad = d >= p.f.n_rows;
+        src = p.f.x + (long long)(pad ? 0 : d) * p.f.ldx;
+        if (p.f.has_ln) {
+          mean[u] = p.f.row_stats[2 * (long long)d];
+          rstd[u] = p.f.row_stats[2 * (long long)d + 1];
+        }
+      } else {
+        src = p.f.x + mc * p.f.ldx;
+        if (p.f.has_ln) {
+          mean[u] = p.stat_in[2 * mc];
+          rstd[u] = p.stat_in[2 * mc + 1];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const float t = src[min(lane + 64 * q, K - 1)];
+        x[u][q] = pad ? 0.f : t;
+      }
+      if (!live[u]) go[u] = 0.f;
+    }
+    float s1[4], s2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s1[u] = s2[u] = 0.f;
+      db += go[u];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const float gw = go[u] * wv[q];                 // zero beyond K (wv) and for rows beyond the block (go)
+        if (p.f.has_ln) {
+          const float xh = (x[u][q] - mean[u]) * rstd[u];
+          aW[q] += (gv[q] * xh + bv[q]) * go[u];
+          aG[q] += gw * xh;
+          aB[q] += gw;
+          s1[u] += gw * gv[q];
+          s2[u] += gw * gv[q] * xh;
+        } else {
+          aW[q] += (lane + 64 * q < K ? x[u][q] : 0.f) * go[u];
+        }
+      }
+    }
+    if (p.has_prev) {
+      if (p.f.has_ln) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s1[u] = wave_sum(s1[u]) * inv_k;
+          s2[u] = wave_sum(s2[u]) * inv_k;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long m = mb + 4 * u;
+        if (!live[u]) continue;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int k = lane + 64 * q;
+          if (k < p.lddz) {
+            float v = 0.f;
+            if (k < K) {
+              const float a = x[u][q];
+              float dx = go[u] * wv[q];
+              if (p.f.has_ln) dx = rstd[u] * (dx * gv[q] - s1[u] - (a - mean[u]) * rstd[u] * s2[u]);
+              v = dx * act_grad_from_out(p.activation, a);
+            }
+            p.dz[m * p.lddz + k] = v;
+          }
+        }
+      }
+    }
+  }
+  float* acc = smem + w * (3 * K + 1);
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = lane + 64 * q;
+    if (k < K) {
+      acc[k] = aW[q];
+      acc[K + k] = aG[q];
+      acc[2 * K + k] = aB[q];
+    }
+  }
+  if (lane == 0) acc[3 * K] = db;
+  __syncthreads();
+  float* out = p.partials + (long long)blockIdx.x * (3 * K + 4);
+  for (int i = threadIdx.x; i < 3 * K + 1; i += blockDim.x) {
+    const int stride = 3 * K + 1;
+    out[i] = smem[i] + smem[stride + i] + smem[2 * stride + i] + smem[3 * stride + i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // wgrad:  G[k][n] = sum_m xhat[m][k] * dz[m][n]   (+ S[n] = sum_m dz[m][n])
-// tile 64 (k) x 64 (n), 4 waves as 2x2; rows m split over blockIdx.z into slabs
+// The contraction runs over rows, so BOTH operands are "k-strided" streams (lanes along the contiguous
+// index, coalesced): no LDS, no barrier.  xhat is the normalised input the forward pass kept, which
+// makes this kernel independent of doc ids and row statistics.  Workgroup = 2 x 2 waves (64 x 64 outputs,
+// each stream shared by two waves through L1); rows are split over blockIdx.x into slabs -- blockIdx.x
+// is the fastest-varying index so that an XCD (workgroup id mod 8) keeps to its own rows of both operands.
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
-  const float* x; int ldx; const int* docids; int n_rows; const float* row_stats;  // gather (layer 0)
-  const float* stat_in;    // dense: [M][2]
-  int has_ln;
+  const float* xhat; int ldx;        // [M][ldx]
   const float* dz; int ldn; int N;   // [M][ldn]
   int K; long long M; int rows_per_split;
   float* gslab;            // [nsplit][K][ldn]
@@ -733,93 +875,82 @@ struct WgradArgs {
 };
 
 __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[2][BK * 64];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int wr = w >> 1, wc = w & 1;
-  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-  const long long m_begin = (long long)blockIdx.z * p.rows_per_split;
+  const int k0 = blockIdx.y * 64 + wr * 32, n0 = blockIdx.z * 64 + wc * 32;
+  const long long m_begin = (long long)blockIdx.x * p.rows_per_split;
   long long m_end = m_begin + p.rows_per_split;
   if (m_end > p.M) m_end = p.M;
-  // staging: 32 rows x 16 float4 per operand = 512 float4 -> two per thread (rows s_row and s_row + 16)
-  const int s_row = tid >> 4, s_c = 4 * (tid & 15);
-  struct Regs {
-    float4 a[2], b[2];
-    float2 st[2];
-    long long m[2];
-  } R0, R1;
-  const int ka = k0 + s_c, nb = n0 + s_c;
-  const int kac = min(ka, p.ldx - 4), nbc = min(nb, p.ldn - 4);
-  auto load_chunk = [&](int chunk, Regs& r) {  // unconditional loads on clamped addresses, masked at store time
+  const int nch = (int)((m_end - m_begin + 31) >> 5);
+  const int kc = min(k0 + l31, p.ldx - 1), nc = min(n0 + l31, p.ldn - 1);
+  const long long m_last = p.M - 1;
+  struct Frag { float a[16], b[16]; } S0, S1, S2;
+  // full chunks: wave-uniform row base + one 32-bit per-lane offset (a vector add per load); the last, partial
+  // chunk of a slab clamps its rows for the load and zeroes them afterwards
+  const unsigned la = (unsigned)(16 * h * p.ldx + kc), lb = (unsigned)(16 * h * p.ldn + nc);
+  auto load = [&](int i, Frag& S) {
+    const long long mc = m_begin + 32 * (long long)min(i, nch - 1);
+    if (mc + 32 <= m_end) {
+      const float* ap = p.xhat + mc * p.ldx;
+      const float* bp = p.dz + mc * p.ldn;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long long m = m_begin + (long long)chunk * BK + s_row + 16 * i;
-      r.m[i] = m;
-      const long long mc = m < m_end ? m : m_end - 1;
-      long long xrow = mc, srow = mc;
-      bool pad = false;
-      if (p.docids) {
-        const int d = p.docids[mc];
-        pad = d >= p.n_rows;
-        xrow = pad ? 0 : d;
-        srow = d;
-      }
-      r.a[i] = *reinterpret_cast<const float4*>(p.x + xrow * p.ldx + kac);
-      r.st[i] = make_float2(0.f, 1.f);
-      if (p.has_ln) {
-        const float* sp = p.docids ? p.row_stats : p.stat_in;
-        r.st[i] = *reinterpret_cast<const float2*>(sp + 2 * srow);
-      }
-      if (pad) r.st[i] = make_float2(0.f, 0.f), r.a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      r.b[i] = *reinterpret_cast<const float4*>(p.dz + mc * p.ldn + nbc);
-    }
-  };
-  auto store_chunk = [&](Regs& r, int buf) {
+      for (int t = 0; t < 16; ++t) S.a[t] = ap[la + (unsigned)t * (unsigned)p.ldx];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float4 x = r.a[i];
-      const float mean = r.st[i].x, rstd = r.st[i].y;  // xhat = (x - mean) * rstd  (mean 0, rstd 1 without LN)
-      x.x = (x.x - mean) * rstd; x.y = (x.y - mean) * rstd;
-      x.z = (x.z - mean) * rstd; x.w = (x.w - mean) * rstd;
-      float4 dzv = r.b[i];
-      const bool row_ok = r.m[i] < m_end;
-      if (!row_ok || ka >= p.K) x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ka + 1 >= p.K) x.y = 0.f;
-      if (ka + 2 >= p.K) x.z = 0.f;
-      if (ka + 3 >= p.K) x.w = 0.f;
-      if (!row_ok || nb >= p.ldn) dzv = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&As[buf][(s_row + 16 * i) * 64 + s_c]) = x;
-      *reinterpret_cast<float4*>(&Bs[buf][(s_row + 16 * i) * 64 + s_c]) = dzv;
+      for (int t = 0; t < 16; ++t) S.b[t] = bp[lb + (unsigned)t * (unsigned)p.ldn];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const long long m = min(mc + 16 * h + t, m_last);
+        S.a[t] = p.xhat[m * p.ldx + kc];
+        S.b[t] = p.dz[m * p.ldn + nc];
+      }
     }
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float colsum = 0.f;
-  const bool do_colsum = blockIdx.x == 0 && tid < 64;
-  auto compute = [&](int buf) {
-    float a[16], b[16];
-    load_frag_kmajor(As[buf], 64, wr * 32 + l31, h, a);
-    load_frag_kmajor(Bs[buf], 64, wc * 32 + l31, h, b);
-    mma16(a, b, acc);
-    if (do_colsum) {
+  const bool do_colsum = blockIdx.y == 0 && wr == 0;
+  auto compute = [&](Frag& S, int i) {
+    const long long mc = m_begin + 32 * (long long)i;
+    if (mc + 32 > m_end) {
 #pragma unroll
-      for (int r = 0; r < BK; ++r) colsum += Bs[buf][r * 64 + tid];
+      for (int t = 0; t < 16; ++t) {
+        const bool ok = mc + 16 * h + t < m_end;
+        S.a[t] = ok ? S.a[t] : 0.f;
+        S.b[t] = ok ? S.b[t] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S.a[t], S.b[t], acc, 0, 0, 0);
+    if (do_colsum) {
+      float s4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s4[q] = (S.b[4 * q] + S.b[4 * q + 1]) + (S.b[4 * q + 2] + S.b[4 * q + 3]);
+      colsum += (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
   };
-  const int nchunk = (int)((m_end - m_begin + BK - 1) / BK);
-#define WG_LOAD(c, R) load_chunk(c, R)
-#define WG_STORE(R, b) store_chunk(R, b)
-#define WG_COMPUTE(b) compute(b)
-  ULTR_GEMM_PIPELINE(nchunk, WG_LOAD, WG_STORE, WG_COMPUTE);
-  float* g = p.gslab + (long long)blockIdx.z * p.K * p.ldn;
-  const int col = n0 + wc * 32 + l31;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int k = k0 + wr * 32 + acc_row(r, h);
-    if (k < p.K && col < p.ldn) g[(long long)k * p.ldn + col] = acc[r];
+#define WG_LOAD(i, S) load(i, S)
+#define WG_COMPUTE(S, i) compute(S, i)
+  if (nch > 0) {
+    load(0, S0);
+    load(1, S1);
+    ULTR_STREAM_GEMM(nch, WG_LOAD, WG_COMPUTE);
   }
-  if (do_colsum && n0 + tid < p.ldn) p.sslab[(long long)blockIdx.z * p.ldn + n0 + tid] = colsum;
+  float* g = p.gslab + (long long)blockIdx.x * p.K * p.ldn;
+  const int col = n0 + l31;
+  if (col < p.ldn) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + acc_row(r, h);
+      if (k < p.K) g[(long long)k * p.ldn + col] = acc[r];
+    }
+  }
+  if (do_colsum) {
+    float other;
+    const float mine = xor32_partner(colsum, &other);  // the two wave halves hold alternate 16-row groups
+    if (h == 0 && col < p.ldn) p.sslab[(long long)blockIdx.x * p.ldn + col] = mine + other;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1031,12 +1162,12 @@ extern "C" int ultr_debug_stamps(long long* host, int n) {
 }
 #endif
 
-template <int WN, int WK, bool FUSE, bool GATHER>
-static int launch_fwd_g(const FwdArgs& a, hipStream_t st) {
+template <int WN, int WK, bool FUSE, bool GATHER, int QMAX>
+static int launch_fwd_q(const FwdArgs& a, hipStream_t st, const char* name) {
   const size_t smem = sizeof(float) * fwd_smem_floats<WN, WK>(a.K, FUSE);
   static bool attr_set = false;  // the panel of a 512-wide layer is already past the 64 KB default
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_layer_kernel<WN, WK, FUSE, GATHER>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("ultr_dnn_forward: cannot raise the dynamic LDS limit");
       return ULTR_EHIP;
@@ -1045,32 +1176,71 @@ static int launch_fwd_g(const FwdArgs& a, hipStream_t st) {
   }
   ULTR_REQUIRE(smem <= 160 * 1024, ULTR_ELIMIT, "ultr_dnn_forward: layer needs %zu bytes of LDS", smem);
   {
-    ultr::ProfScope prof_("fwd_layer_kernel", st);
-    hipLaunchKernelGGL((fwd_layer_kernel<WN, WK, FUSE, GATHER>), dim3((unsigned)cdiv(a.M, 32), (unsigned)cdiv(a.N, 32 * WN)),
+    ultr::ProfScope prof_(name, st);
+    hipLaunchKernelGGL((fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX>), dim3((unsigned)cdiv(a.M, 32), (unsigned)cdiv(a.N, 32 * WN)),
                        dim3(64 * WN * WK), smem, st, a);
   }
-  return check_launch("fwd_layer_kernel");
+  return check_launch(name);
+}
+template <int WN, int WK, bool FUSE, bool GATHER>
+static int launch_fwd_g(const FwdArgs& a, hipStream_t st, const char* name) {
+  return a.K <= 512 ? launch_fwd_q<WN, WK, FUSE, GATHER, 2>(a, st, name) : launch_fwd_q<WN, WK, FUSE, GATHER, 4>(a, st, name);
 }
 template <int WN, int WK, bool FUSE>
-static int launch_fwd(const FwdArgs& a, hipStream_t st) {
-  return a.docids ? launch_fwd_g<WN, WK, FUSE, true>(a, st) : launch_fwd_g<WN, WK, FUSE, false>(a, st);
+static int launch_fwd(const FwdArgs& a, hipStream_t st, const char* name) {
+  if constexpr (FUSE) return launch_fwd_g<WN, WK, FUSE, false>(a, st, name);  // the fused variants are built for dense inputs only
+  else
+  return a.docids ? launch_fwd_g<WN, WK, FUSE, true>(a, st, name) : launch_fwd_g<WN, WK, FUSE, false>(a, st, name);
 }
 // Pick the wave arrangement: about one 32x32 tile per SIMD-slot of the chip (1024 waves), splitting the
 // contraction inside the workgroup when the layer has fewer tiles than that.
-static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st) {
+static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st, const char* name = "fwd_layer_kernel") {
   const long long tilesM = cdiv(a.M, 32), tilesN = cdiv(a.N, 32);
   const int chunks = (int)cdiv(a.K < kPanelMaxK ? a.K : kPanelMaxK, 32);
   if (fuse) {
     const int WN = tilesN <= 1 ? 1 : tilesN <= 2 ? 2 : 4;
     const int WK = (tilesM * WN < 1024 && chunks >= 4) ? 2 : 1;
-    if (WN == 1) return WK == 1 ? launch_fwd<1, 1, true>(a, st) : launch_fwd<1, 2, true>(a, st);
-    if (WN == 2) return WK == 1 ? launch_fwd<2, 1, true>(a, st) : launch_fwd<2, 2, true>(a, st);
-    return WK == 1 ? launch_fwd<4, 1, true>(a, st) : launch_fwd<4, 2, true>(a, st);
+    if (WN == 1) return WK == 1 ? launch_fwd<1, 1, true>(a, st, name) : launch_fwd<1, 2, true>(a, st, name);
+    if (WN == 2) return WK == 1 ? launch_fwd<2, 1, true>(a, st, name) : launch_fwd<2, 2, true>(a, st, name);
+    return WK == 1 ? launch_fwd<4, 1, true>(a, st, name) : launch_fwd<4, 2, true>(a, st, name);
   }
   const long long base = tilesM * tilesN;
-  if (base >= 1024 || chunks < 4) return launch_fwd<4, 1, false>(a, st);
-  if (base * 2 >= 1024 || chunks < 8) return launch_fwd<2, 2, false>(a, st);
-  return launch_fwd<1, 4, false>(a, st);
+  if (base >= 1024 || chunks < 4) return launch_fwd<4, 1, false>(a, st, name);
+  if (base * 2 >= 1024 || chunks < 8) return launch_fwd<2, 2, false>(a, st, name);
+  return launch_fwd<1, 4, false>(a, st, name);
+}
+
+// ---- fork / join inside the backward pass ------------------------------------------------------
+// wgrad_j depends only on dz_j, not on the dgrad -> row-pass chain that produces dz_{j-1}: it runs on a
+// side stream (a parallel branch when the caller's stream is being captured into a hipGraph), and the
+// finalize kernel joins everything.  Streams and events are created on first use, per device.
+struct SideStreams {
+  hipStream_t side[2];
+  hipEvent_t ready[ULTR_MAX_LAYERS + 1];  // recorded on the caller's stream when dz_j is complete
+  hipEvent_t done[ULTR_MAX_LAYERS + 1];   // recorded on a side stream when wgrad_j is complete
+  bool ok;
+};
+static SideStreams* side_streams() {
+  // Opt-in (ULTR_FORK=1): measured on MI355X, a hipGraph with parallel branches replays ~10 us SLOWER per step at
+  // the headline size than the same kernels in one chain (cross-queue dependencies cost more than these
+  // 10-20 us kernels can win back); it pays only for much larger batches.
+  static const bool enabled = [] { const char* e = getenv("ULTR_FORK"); return e && e[0] == '1'; }();
+  if (!enabled) return nullptr;
+  static SideStreams per_dev[64];
+  static bool made[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStreams& S = per_dev[dev];
+  if (!made[dev]) {
+    made[dev] = true;
+    S.ok = true;
+    for (int i = 0; i < 2; ++i) S.ok = S.ok && hipStreamCreateWithFlags(&S.side[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i <= ULTR_MAX_LAYERS; ++i) {
+      S.ok = S.ok && hipEventCreateWithFlags(&S.ready[i], hipEventDisableTiming) == hipSuccess;
+      S.ok = S.ok && hipEventCreateWithFlags(&S.done[i], hipEventDisableTiming) == hipSuccess;
+    }
+  }
+  return S.ok ? &S : nullptr;
 }
 
 static int check_desc(const UltrDnnDesc* d, const char* who) {
@@ -1152,7 +1322,8 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
     a.W = params + desc->off_W[j]; a.bias = params + desc->off_b[j];
     a.K = L.K[j]; a.N = L.N[j]; a.ldn = L.ldn[j]; a.M = M; a.activation = desc->activation;
     a.act_out = ws + L.act[j];
-    const bool fuse = j == L.H - 1 && L.N[j] <= 128;  // the last hidden layer also produces the scores
+    a.xhat_out = ws + L.xhat[j]; a.ldxh = round4(L.K[j]);
+    const bool fuse = j == L.H - 1 && j > 0 && L.N[j] <= 128;  // the last hidden layer also produces the scores
     if (fuse) {
       a.out_gamma = params + desc->off_gamma[L.H]; a.out_beta = params + desc->off_beta[L.H];
       a.out_W = params + desc->off_W[L.H]; a.out_bias = params + desc->off_b[L.H];
@@ -1161,7 +1332,7 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
     rc = launch_fwd_layer(a, fuse, st);
     if (rc) return rc;
   }
-  if (L.H > 0 && L.N[L.H - 1] <= 128) return ULTR_OK;  // scores came out of the fused epilogue
+  if (L.H > 1 && L.N[L.H - 1] <= 128) return ULTR_OK;  // scores came out of the fused epilogue
   OutArgs o{};
   const int j = L.H;
   if (j == 0) {
@@ -1190,10 +1361,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
   float* ws = reinterpret_cast<float*>(workspace);
   const int has_ln = desc->norm == ULTR_NORM_LAYER;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)desc->n_params, st) != hipSuccess) {
-    set_error("ultr_dnn_backward: hipMemsetAsync failed");
-    return ULTR_EHIP;
-  }
+  ULTR_REQUIRE((desc->n_params & 3) == 0, ULTR_EINVAL, "ultr_dnn_backward: n_params=%lld must be a multiple of 4", desc->n_params);
   const int H = L.H;
   int cur = 0;  // which dz buffer holds the gradient wrt the current layer's output
   {
@@ -1212,39 +1380,65 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
     b.d_scores = d_scores; b.activation = desc->activation; b.has_prev = H > 0;
     b.dz = ws + L.dz[cur]; b.lddz = H > 0 ? L.ldn[H - 1] : 0;
     b.rows_per_block = L.out_rows_per_block; b.partials = ws + L.outpart;
+    b.zero = grads; b.zero_n4 = desc->n_params / 4;  // cleared by the first kernel of the pass, filled by the last
     const size_t smem = sizeof(float) * 4 * (3 * (size_t)L.K[H] + 1);
     ULTR_REQUIRE(smem <= 64 * 1024, ULTR_ELIMIT, "ultr_dnn_backward: output layer input width %d too large", L.K[H]);
+    ULTR_REQUIRE(H == 0 || L.K[H] <= 1024, ULTR_ELIMIT, "ultr_dnn_backward: hidden width %d beyond %d", L.K[H], 1024);
     {
       ultr::ProfScope prof_("bwd_out_kernel", st);
-      hipLaunchKernelGGL(bwd_out_kernel, dim3((unsigned)L.out_blocks), dim3(kThreads), smem, st, b);
+      const dim3 grid((unsigned)L.out_blocks), block(kThreads);
+      if (L.K[H] <= 128) hipLaunchKernelGGL(bwd_out_kernel<2>, grid, block, smem, st, b);
+      else if (L.K[H] <= 256) hipLaunchKernelGGL(bwd_out_kernel<4>, grid, block, smem, st, b);
+      else if (L.K[H] <= 1024) hipLaunchKernelGGL(bwd_out_kernel<16>, grid, block, smem, st, b);
+      else hipLaunchKernelGGL(bwd_out_wide_kernel, grid, block, smem, st, b);
     }
     rc = check_launch("bwd_out_kernel");
     if (rc) return rc;
   }
+  // fork / join: see side_streams().  With per-kernel timing on everything stays on the caller's stream.
+  SideStreams* SS = ultr::g_profile_on ? nullptr : side_streams();
+  unsigned pending = 0;  // layers whose wgrad is still running on a side stream
+#define ULTR_HIP_OK(call)                                                        \
+  do {                                                                           \
+    if ((call) != hipSuccess) {                                                  \
+      set_error("ultr_dnn_backward: %s failed", #call);                          \
+      return ULTR_EHIP;                                                          \
+    }                                                                            \
+  } while (0)
   for (int j = H - 1; j >= 0; --j) {
     WgradArgs g{};
-    if (j == 0) {
-      g.x = table; g.ldx = ldx; g.docids = docids; g.n_rows = n_rows; g.row_stats = table_stats;
-    } else {
-      g.x = ws + L.act[j - 1]; g.ldx = L.ldn[j - 1]; g.stat_in = ws + L.stat[j];
-    }
-    g.has_ln = has_ln;
+    g.xhat = ws + L.xhat[j]; g.ldx = round4(L.K[j]);
     g.dz = ws + L.dz[cur]; g.ldn = L.ldn[j]; g.N = L.N[j];
     g.K = L.K[j]; g.M = M; g.rows_per_split = L.rows_per_split[j];
     g.gslab = ws + L.gslab[j]; g.sslab = ws + L.sslab[j];
+    hipStream_t wst = st;
+    if (SS && j > 0) {  // layer 0's wgrad is the tail of the critical path itself
+      wst = SS->side[j & 1];
+      ULTR_HIP_OK(hipEventRecord(SS->ready[j], st));
+      ULTR_HIP_OK(hipStreamWaitEvent(wst, SS->ready[j], 0));
+    }
     {
-      ultr::ProfScope prof_("wgrad_kernel", st);
-      hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64), (unsigned)L.nsplit[j]),
-                       dim3(kThreads), 0, st, g);
+      ultr::ProfScope prof_("wgrad_kernel", wst);
+      hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)L.nsplit[j], (unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64)),
+                       dim3(kThreads), 0, wst, g);
     }
     rc = check_launch("wgrad_kernel");
     if (rc) return rc;
+    if (wst != st) {
+      ULTR_HIP_OK(hipEventRecord(SS->done[j], wst));
+      pending |= 1u << j;
+    }
     if (j > 0) {
+      const int nxt = (cur + 1) % 3;
+      if (j + 2 < H && (pending & (1u << (j + 2)))) {  // dz_{j+2} lives in the buffer dgrad_j is about to overwrite
+        ULTR_HIP_OK(hipStreamWaitEvent(st, SS->done[j + 2], 0));
+        pending &= ~(1u << (j + 2));
+      }
       DgradArgs d{};
       d.dz = ws + L.dz[cur]; d.ldn = L.ldn[j]; d.N = L.N[j];
       d.W = params + desc->off_W[j];
       d.K = L.K[j]; d.ldk = L.ldn[j - 1]; d.M = M;
-      d.dh = ws + L.dz[cur ^ 1];
+      d.dh = ws + L.dz[nxt];
       {
         ultr::ProfScope prof_("dgrad_kernel", st);
         hipLaunchKernelGGL(dgrad_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128)), dim3(kThreads), 0,
@@ -1253,7 +1447,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       rc = check_launch("dgrad_kernel");
       if (rc) return rc;
       RowpassArgs r{};
-      r.dh = ws + L.dz[cur ^ 1]; r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
+      r.dh = ws + L.dz[nxt]; r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
       r.a = ws + L.act[j - 1]; r.stat = ws + L.stat[j]; r.gamma = params + desc->off_gamma[j];
       r.has_ln = has_ln; r.activation = desc->activation;
       {
@@ -1262,9 +1456,12 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       }
       rc = check_launch("rowpass_kernel");
       if (rc) return rc;
-      cur ^= 1;
+      cur = nxt;
     }
   }
+  for (int j = 0; j < H; ++j)
+    if (pending & (1u << j)) ULTR_HIP_OK(hipStreamWaitEvent(st, SS->done[j], 0));
+#undef ULTR_HIP_OK
   FinalizeArgs f{};
   f.H = H;
   int start = 0;

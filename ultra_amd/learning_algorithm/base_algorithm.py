@@ -17,6 +17,7 @@ N*B lists.
 from abc import ABC, abstractmethod
 
 import numpy as np
+import os
 import torch
 
 from .. import _lib
@@ -229,6 +230,15 @@ class BaseAlgorithm(ABC):
         self._train_bufs = tb
         return tb
 
+    # opt-in: a parallel hipGraph branch costs more than the 19 us metric kernel wins back at batch 256
+    side_metrics = os.environ.get('ULTR_SIDE_METRICS', '0') == '1'
+
+    def _side_stream(self):
+        s = getattr(self, '_side', None)
+        if s is None:
+            s = self._side = torch.cuda.Stream(device=self.device)
+        return s
+
     def _all_reduce(self, tb):
         if self.world > 1:
             torch.distributed.all_reduce(tb['bucket'][:tb['n_reduce']])
@@ -271,10 +281,22 @@ class BaseAlgorithm(ABC):
         tb = self._train_buffers(batch.B)
         scores = self.ranking_model(L, batch, tb['scores'])
         self._loss(tb, batch, scores)                          # d_scores + additive statistics
-        self.model.backward(tb['d_scores'], tb['grads'])       # flat un-normalised gradient
+        # The in-step metrics need only the scores and the list weights: they run on a side stream (a parallel
+        # branch of the hipGraph when the step is captured) next to the backward pass, and are joined before
+        # the all-reduce, which carries them together with the gradient and the loss statistics.
+        if self.side_metrics:
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS)
+            self.model.backward(tb['d_scores'], tb['grads'])   # flat un-normalised gradient
+            main.wait_stream(side)
+        else:
+            self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS)
+            self.model.backward(tb['d_scores'], tb['grads'])
         self._all_reduce(tb)                                   # DP: one collective per step
         self._update(tb, batch)                                # EM state, clip + Adagrad
-        self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS)
         fetch = self._publish(tb)
         self.global_step.value += 1
         n_stats, n_met, world = self.n_stats, self.train_plan.n_out, float(self.world)
