@@ -19,6 +19,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import sys
 import time
 
@@ -51,13 +52,22 @@ def train_flops_per_list(F, L):
     return L * (6 * pw - 2 * F * 512)
 
 
-def kernel_flops_per_launch(name, F, M):
-    dims = [(F, 512), (512, 256), (256, 128)]
-    if name in ('fwd_layer_kernel', 'wgrad_kernel'):
-        return 2.0 * M * sum(k * n for k, n in dims) / 3.0, 3
-    if name == 'dgrad_kernel':
-        return 2.0 * M * sum(k * n for k, n in dims[1:]) / 2.0, 2
-    return None, 0
+def kernel_flops_per_launch(name, M):
+    """GEMM launches are reported as '<kernel>/K<k>N<n>' (csrc/dnn.hip): 2 M k n flops each."""
+    m = re.search(r'/K(\d+)N(\d+)$', name)
+    if not m:
+        return None
+    return 2.0 * M * int(m.group(1)) * int(m.group(2))
+
+
+def measured_traffic(kernel):
+    """HBM-side bytes per launch from the committed PMC passes (tools/collect_profiles.sh, tools/make_traffic.py)."""
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_traffic.json')) \
+        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+    if not files:
+        return None
+    ent = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))['kernels'].get(kernel)
+    return ent['hbm_bytes'] if ent else None
 
 
 def build_world(cfg, args, device):
@@ -220,14 +230,14 @@ def main():
         lib.ultr_profile_report(buf, len(buf))
         lib.ultr_profile_enable(0)
         for line in buf.value.decode().strip().split('\n'):
-            name, cnt, ms = line.split()
+            name, cnt, ms = line.rsplit(None, 2)
             kernels[name] = (int(cnt), float(ms))
         M = args.batch * cfg['L']
         best = None
         tot_ms = sum(ms for _, ms in kernels.values())
         for name, (cnt, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
-            fl, _ = kernel_flops_per_launch(name, cfg['F'], M)
-            log('  %-28s %6d launches  %9.3f us/launch  %8.3f us/step  %5.1f%%%s' % (
+            fl = kernel_flops_per_launch(name, M)
+            log('  %-52s %5d launches  %8.3f us/launch  %8.3f us/step  %5.1f%%%s' % (
                 name, cnt, 1e3 * ms / cnt, 1e3 * ms / nprof, 100 * ms / tot_ms,
                 '' if fl is None else '  %.1f TFLOP/s' % (fl / (ms / cnt * 1e-3) / 1e12)))
             if fl is not None and best is None:
@@ -236,9 +246,10 @@ def main():
         if best:
             name, fl, ms = best
             achieved = fl / (ms * 1e-3) / 1e12
-            roofline = {'kernel': name, 'bound': 'mfma', 'achieved': round(achieved, 3),
+            kname = name.split('/')[0]
+            roofline = {'kernel': kname, 'gemm': name.split('/')[1], 'bound': 'mfma', 'achieved': round(achieved, 3),
                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': measured_traffic(kname),
                         'launch_us': round(1e3 * ms, 3), 'flops_per_launch': fl}
 
     out = {

@@ -24,6 +24,7 @@ int check_launch(const char* what);
 // ---- opt-in per-kernel timing (ultr_profile_enable): HIP events around every launch, on the launch
 // stream.  Off by default: one predictable branch per launch.
 extern bool g_profile_on;
+const char* profile_intern(const char* fmt, ...);
 void profile_begin(const char* name, hipStream_t s, void** handle);
 void profile_end(void* handle, hipStream_t s);
 struct ProfScope {

@@ -37,6 +37,20 @@ struct ProfRec {
 static std::vector<ProfRec*> g_recs;
 static std::mutex g_prof_mu;
 
+// stable storage for profile names composed at run time (template arguments, layer shape)
+const char* profile_intern(const char* fmt, ...) {
+  static std::map<std::string, std::string*> names;
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  auto it = names.find(buf);
+  if (it == names.end()) it = names.emplace(buf, new std::string(buf)).first;
+  return it->second->c_str();
+}
+
 void profile_begin(const char* name, hipStream_t s, void** handle) {
   ProfRec* r = new ProfRec();
   r->name = name;

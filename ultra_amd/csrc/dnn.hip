@@ -1175,6 +1175,9 @@ static int launch_fwd_q(const FwdArgs& a, hipStream_t st, const char* name) {
     attr_set = true;
   }
   ULTR_REQUIRE(smem <= 160 * 1024, ULTR_ELIMIT, "ultr_dnn_forward: layer needs %zu bytes of LDS", smem);
+  if (ultr::g_profile_on)  // name the instantiation and the GEMM shape the way rocprofv3 sees the kernel
+    name = ultr::profile_intern("%s<%d, %d, %s, %s, %d>/K%dN%d", name, WN, WK, FUSE ? "true" : "false", GATHER ? "true" : "false",
+                                QMAX, a.K, a.N);
   {
     ultr::ProfScope prof_(name, st);
     hipLaunchKernelGGL((fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX>), dim3((unsigned)cdiv(a.M, 32), (unsigned)cdiv(a.N, 32 * WN)),
@@ -1418,7 +1421,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       ULTR_HIP_OK(hipStreamWaitEvent(wst, SS->ready[j], 0));
     }
     {
-      ultr::ProfScope prof_("wgrad_kernel", wst);
+      ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_kernel/K%dN%d", L.K[j], L.N[j]) : "wgrad_kernel", wst);
       hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)L.nsplit[j], (unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64)),
                        dim3(kThreads), 0, wst, g);
     }
@@ -1440,7 +1443,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       d.K = L.K[j]; d.ldk = L.ldn[j - 1]; d.M = M;
       d.dh = ws + L.dz[nxt];
       {
-        ultr::ProfScope prof_("dgrad_kernel", st);
+        ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("dgrad_kernel/K%dN%d", L.K[j], L.N[j]) : "dgrad_kernel", st);
         hipLaunchKernelGGL(dgrad_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128)), dim3(kThreads), 0,
                          st, d);
       }

@@ -21,7 +21,7 @@ import random
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, parallel
 from ..learning_algorithm.base_algorithm import DeviceBatch, DEVICE_BATCH_KEY
 from ..utils import click_models as cm
 from ..utils import hparams as hp
@@ -91,7 +91,7 @@ class ClickSimulationFeed(BaseInputFeed):
             _lib.ptr(dd.initial_list), _lib.ptr(dd.labels), dd.Q, dd.Lmax, self.rank_list_size, B, self.kind,
             _lib.ptr(self.exam), self.exam.numel(), _lib.ptr(self.click_prob), self.click_prob.numel(), mode,
             int(self.hparams.seed) & 0xFFFFFFFFFFFFFFFF, 0, _lib.ptr(self.step_ctr) if mode == 0 else None,
-            self.rank * B, _lib.ptr(uniforms), n_cand, slot_start, 1 if check_validation else 0,
+            parallel.slot_base(self.rank, B), _lib.ptr(uniforms), n_cand, slot_start, 1 if check_validation else 0,
             self.MAX_SAMPLE_ROUND_NUM, dd.n_rows, _lib.ptr(o['docids']), _lib.ptr(o['clicks']), _lib.ptr(o['idx']),
             _lib.ptr(self.info), _lib.current_stream()), 'ultr_batch_assemble')
 

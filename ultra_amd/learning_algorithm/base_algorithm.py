@@ -20,7 +20,7 @@ import numpy as np
 import os
 import torch
 
-from .. import _lib
+from .. import _lib, parallel
 from ..utils import data_utils, find_class, hparams as hp, metrics as dev_metrics
 from ..ranking_model.DNN import feature_row_stats
 
@@ -240,8 +240,7 @@ class BaseAlgorithm(ABC):
         return s
 
     def _all_reduce(self, tb):
-        if self.world > 1:
-            torch.distributed.all_reduce(tb['bucket'][:tb['n_reduce']])
+        parallel.all_reduce_bucket(tb['bucket'], tb['n_reduce'], self.world)
 
     def _train_metrics(self, tb, batch, scores, weighted):
         u = getattr(self, 'metric_uniforms', None)  # [B, L] tie-break uniforms supplied by the caller (tests)
