@@ -16,6 +16,7 @@ plain + weighted).  Rank 0 prints ONE JSON line (contract in the task statement)
                   feed loop (oracle/, kind "port"), on a bounded sample, rank 0 at N=1 only.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -166,7 +167,8 @@ def main():
     if world > 1:
         torch.distributed.init_process_group('nccl', device_id=device)
     cfg = CONFIGS[args.config]
-    data, exp, model, feed = build_world(cfg, args, device)
+    with contextlib.redirect_stdout(sys.stderr):  # the plugin classes print progress lines like the reference does
+        data, exp, model, feed = build_world(cfg, args, device)
     use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 0)
 
     def step():

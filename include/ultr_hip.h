@@ -229,6 +229,16 @@ int ultr_clip_adagrad(float* theta, float* acc, const float* grads, long long n,
                       float scale_const, float l2, float clip_norm, float lr, int strategy,
                       float* out_norm, float* ws, void* stream);
 
+/* The same, plus a second, small parameter group (n_s <= 4096) with its own normaliser, clip norm and
+ * learning rate, updated inside the first launch: DLA updates the ranker and the propensity tower with two
+ * independent clip_by_global_norm + optimiser pairs (dla.py:240-251), which would otherwise cost a third
+ * kernel per step for 11 floats.  The main group must have more than 4096 parameters. */
+int ultr_clip_adagrad2(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                       float scale_const, float l2, float clip_norm, float lr, int strategy, float* out_norm,
+                       float* ws, float* theta_s, float* acc_s, const float* grads_s, int n_s,
+                       const float* denom_s, float scale_const_s, float l2_s, float clip_norm_s, float lr_s,
+                       float* out_norm_s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,66 @@ __device__ __forceinline__ bool last_block_arrive(unsigned int* counter, unsigne
   return s_last != 0u;
 }
 
+// Column sums (max for columns >= max_from) of the partial rows [G][ns] the blocks of a launch left behind, by
+// the last block, with ALL its threads: thread (rg, s) takes rows rg, rg + RG, ... of column s, four independent
+// loads at a time, and the RG partials of a column meet in LDS in fixed order.  A thread that walks the rows of
+// its column alone pays one L2 round trip per row (~0.3 us each: measured 5 us for 16 rows, tools/fenceprobe.hip).
+// s_tmp: blockDim.x floats of LDS; the totals land in s_out[0..ns).  Requires ns <= blockDim.x.
+__device__ __forceinline__ void reduce_rows(const float* __restrict__ rows, int G, int ns, int max_from, float* s_tmp,
+                                            float* s_out) {
+  const int NT = blockDim.x, RG = NT / ns;
+  const int s = threadIdx.x % ns, rg = threadIdx.x / ns;
+  const bool is_max = s >= max_from;
+  float acc = is_max ? -INFINITY : 0.f;
+  if (rg < RG) {
+    for (int b0 = rg; b0 < G; b0 += 4 * RG) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = rows[(long long)min(b0 + u * RG, G - 1) * ns + s];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (b0 + u * RG < G) acc = is_max ? fmaxf(acc, v[u]) : acc + v[u];
+    }
+  }
+  __syncthreads();
+  s_tmp[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < ns) {
+    float r = s_tmp[threadIdx.x];
+    for (int g = 1; g < RG; ++g) r = is_max ? fmaxf(r, s_tmp[g * ns + threadIdx.x]) : r + s_tmp[g * ns + threadIdx.x];
+    s_out[threadIdx.x] = r;
+  }
+  __syncthreads();
+}
+
+// The same hand-off WITHOUT cache maintenance.  The release / acquire fences above write back and invalidate the
+// whole L2 of the XCD; measured on MI355X (tools/fenceprobe.hip) they add 3 us to a 16-block kernel and 15 us to a
+// 64-block one.  Here every handed-off word is written with st_agent() (an sc1 store: it bypasses the
+// non-coherent L2 path) and read with ld_agent() (an sc1 load), the counter is an agent-scope atomic, and no
+// fence is needed: the storing waves drain their stores (vmcnt(0)) before the workgroup barrier that precedes the
+// add, and the last block loads only after its add has returned and its own barrier.
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool last_block_arrive_sc1(unsigned int* counter, unsigned int n_blocks) {
+  __shared__ unsigned int s_last_sc1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int last = (t == n_blocks - 1) ? 1u : 0u;
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last_sc1 = last;
+  }
+  __syncthreads();
+  return s_last_sc1 != 0u;
+}
+
 // ---- Philox4x32-10 -------------------------------------------------------------------------
 struct Philox4 {
   uint32_t v[4];

@@ -20,6 +20,7 @@
 //    LayerNorm backward and the activation derivative (from the stored activation output).
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace ultr {
 
@@ -1033,29 +1034,48 @@ struct RowpassArgs {
   int has_ln; int activation;
 };
 
+// Register-resident: every load of a row (dh, a, gamma, statistics) is issued before the first use, so the row
+// costs one memory round trip instead of one per 64-column step; KQ = columns per lane.
+template <int KQ>
 __global__ void __launch_bounds__(kThreads) rowpass_kernel(RowpassArgs p) {
   const int lane = threadIdx.x & 63;
   const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= p.M) return;
   float* row = p.dh + m * p.ldk;
   const float* a = p.a + m * p.ldk;
-  float mean = 0.f, rstd = 1.f, c1 = 0.f, c2 = 0.f;
+  float dv[KQ], av[KQ], gv[KQ];
+  float mean = 0.f, rstd = 1.f;
   if (p.has_ln) {
     mean = p.stat[2 * m];
     rstd = p.stat[2 * m + 1];
-    for (int k = lane; k < p.K; k += 64) {
-      const float g = row[k] * p.gamma[k];
+  }
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int kc = min(lane + 64 * q, p.K - 1);
+    dv[q] = row[kc];
+    av[q] = a[kc];
+    gv[q] = p.has_ln ? p.gamma[kc] : 1.f;
+  }
+  float c1 = 0.f, c2 = 0.f;
+  if (p.has_ln) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const bool ok = lane + 64 * q < p.K;
+      const float g = ok ? dv[q] * gv[q] : 0.f;
       c1 += g;
-      c2 += g * (a[k] - mean) * rstd;
+      c2 += g * (av[q] - mean) * rstd;
     }
     c1 = wave_sum(c1) / (float)p.K;
     c2 = wave_sum(c2) / (float)p.K;
   }
-  for (int k = lane; k < p.K; k += 64) {
-    const float ak = a[k];
-    float dx = row[k];
-    if (p.has_ln) dx = rstd * (dx * p.gamma[k] - c1 - (ak - mean) * rstd * c2);
-    row[k] = dx * act_grad_from_out(p.activation, ak);
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = lane + 64 * q;
+    if (k < p.K) {
+      float dx = dv[q];
+      if (p.has_ln) dx = rstd * (dx * gv[q] - c1 - (av[q] - mean) * rstd * c2);
+      row[k] = dx * act_grad_from_out(p.activation, av[q]);
+    }
   }
 }
 
@@ -1208,8 +1228,18 @@ static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st, const c
     return WK == 1 ? launch_fwd<4, 1, true>(a, st, name) : launch_fwd<4, 2, true>(a, st, name);
   }
   const long long base = tilesM * tilesN;
-  if (base >= 1024 || chunks < 4) return launch_fwd<4, 1, false>(a, st, name);
-  if (base * 2 >= 1024 || chunks < 8) return launch_fwd<2, 2, false>(a, st, name);
+  const char* v = getenv("ULTR_FWD_VARIANT");  // experiment switch: "41", "22", "14", "42", "81"
+  if (v) {
+    if (!strcmp(v, "41")) return launch_fwd<4, 1, false>(a, st, name);
+    if (!strcmp(v, "22")) return launch_fwd<2, 2, false>(a, st, name);
+    if (!strcmp(v, "14")) return launch_fwd<1, 4, false>(a, st, name);
+    if (!strcmp(v, "42")) return launch_fwd<4, 2, false>(a, st, name);
+    if (!strcmp(v, "81")) return launch_fwd<8, 1, false>(a, st, name);
+  }
+  // measured at M = 2560 (tools/kbench, rocprofv3): layer 0 (K136 N512) 8x1 13.1 us, 4x1 14.7, 4x2 18.5, 2x2 20.7;
+  // layer 1 (K512 N256) 4x2 18.7 us, 2x2 21.7, 4x1 22.8, 8x1 32.5 -- wider workgroups share one staged panel
+  if (base >= 1024 || chunks < 4) return tilesN >= 8 ? launch_fwd<8, 1, false>(a, st, name) : launch_fwd<4, 1, false>(a, st, name);
+  if (base * 2 >= 1024 || chunks < 8) return tilesN >= 4 ? launch_fwd<4, 2, false>(a, st, name) : launch_fwd<2, 2, false>(a, st, name);
   return launch_fwd<1, 4, false>(a, st, name);
 }
 
@@ -1455,7 +1485,10 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       r.has_ln = has_ln; r.activation = desc->activation;
       {
         ultr::ProfScope prof_("rowpass_kernel", st);
-        hipLaunchKernelGGL(rowpass_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, r);
+        const dim3 rgrid((unsigned)cdiv(M, 4)), rblock(kThreads);
+        if (r.K <= 256) hipLaunchKernelGGL(rowpass_kernel<4>, rgrid, rblock, 0, st, r);
+        else if (r.K <= 512) hipLaunchKernelGGL(rowpass_kernel<8>, rgrid, rblock, 0, st, r);
+        else hipLaunchKernelGGL(rowpass_kernel<16>, rgrid, rblock, 0, st, r);
       }
       rc = check_launch("rowpass_kernel");
       if (rc) return rc;

@@ -119,10 +119,17 @@ __global__ void __launch_bounds__(256) assemble_slots_kernel(const int* __restri
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const uint32_t slot = slot_base + (uint32_t)b;
     const unsigned long long lmask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
-    int i = 0, doc = -1, attempts = 0;
+    // Rejection sampling is a serial chain of dependent loads per attempt (list row -> labels -> click tables),
+    // and the step waits for the unluckiest slot.  Attempts are independent Philox streams (keyed by the attempt
+    // index), so the wave evaluates G = 64 / P of them AT ONCE (P = lanes per attempt) and takes the first one
+    // the sequential rule would have taken: same draws, same result, one round of loads in >99 % of the slots.
+    const int P = L <= 16 ? 16 : L <= 32 ? 32 : 64, G = 64 / P;
+    const int ai = lane / P, pos = lane % P;
+    int i = 0, doc = -1, attempts = 0, gsel = 0;
     float lab = 0.f;
     unsigned long long mask = 0ull;
-    for (int a = 0; a < max_attempts; ++a) {
+    for (int a0 = 0; a0 < max_attempts; a0 += G) {
+      const int a = a0 + ai;
       // draw 0 (words 0,1 of block 0) picks the list: int(random.random() * length) (:132)
       const Philox4 b0 = philox4x32_10(slot, (uint32_t)a, 0u, step, k0, k1);
       i = (int)(u53(b0.v[0], b0.v[1]) * (double)Q);
@@ -130,32 +137,42 @@ __global__ void __launch_bounds__(256) assemble_slots_kernel(const int* __restri
       bool c = false;
       doc = -1;
       lab = 0.f;
-      if (lane < L) {
-        doc = initial_list[(long long)i * Lmax + lane];
-        lab = doc < 0 ? 0.f : labels[(long long)i * Lmax + lane];  // :80-82
+      if (pos < L && a < max_attempts) {
+        doc = initial_list[(long long)i * Lmax + pos];
+        lab = doc < 0 ? 0.f : labels[(long long)i * Lmax + pos];  // :80-82
         if (click_model == ULTR_CLICK_ORACLE) {
           c = lab != 0.f;
         } else {
-          const int d = 1 + lane;  // draws 1..L are the click draws (:87)
+          const int d = 1 + pos;  // draws 1..L are the click draws (:87)
           const Philox4 bd = philox4x32_10(slot, (uint32_t)a, (uint32_t)(d >> 1), step, k0, k1);
           const double u = (d & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
-          c = u < click_threshold(t, lane, lab);
+          c = u < click_threshold(t, pos, lab);
         }
       }
-      mask = __ballot(c) & lmask;
-      if (click_model == ULTR_CLICK_CASCADE) mask &= (~mask + 1ull);  // only the first click counts
-      attempts = a + 1;
-      if (!check_validation || mask != 0ull) break;
+      const unsigned long long bal = __ballot(c);
+      bool done = false;
+      for (int g = 0; g < G && !done; ++g) {  // wave-uniform: the first attempt of this round that is accepted
+        if (a0 + g >= max_attempts) break;
+        unsigned long long mg = (P == 64 ? bal : (bal >> (g * P))) & lmask;
+        if (click_model == ULTR_CLICK_CASCADE) mg &= (~mg + 1ull);  // only the first click counts
+        if (!check_validation || mg != 0ull || a0 + g == max_attempts - 1) {
+          done = true;
+          gsel = g;
+          mask = mg;
+          attempts = a0 + g + 1;
+        }
+      }
+      if (done) break;
     }
-    if (lane < L) {
-      out_docids[(long long)lane * B + b] = doc < 0 ? n_rows : doc;  // pad -> the zero row (:140-143)
-      float cv = ((mask >> lane) & 1ull) ? 1.f : 0.f;
+    if (ai == gsel && pos < L) {
+      out_docids[(long long)pos * B + b] = doc < 0 ? n_rows : doc;  // pad -> the zero row (:140-143)
+      float cv = ((mask >> pos) & 1ull) ? 1.f : 0.f;
       if (click_model == ULTR_CLICK_ORACLE) cv = lab;
-      out_clicks[(long long)lane * B + b] = cv;
-    }
-    if (lane == 0) {
-      out_list_idx[b] = i;
-      atomicAdd(&info[2], attempts);  // diagnostic: acceptance rate = B / total attempts
+      out_clicks[(long long)pos * B + b] = cv;
+      if (pos == 0) {
+        out_list_idx[b] = i;
+        atomicAdd(&info[2], attempts);  // diagnostic: acceptance rate = B / total attempts
+      }
     }
   }
   if (step_ctr) {

@@ -49,15 +49,21 @@ __device__ __forceinline__ bool finish_stats(float* s_acc, int ns, int max_from,
   for (int s = threadIdx.x; s < ns; s += blockDim.x) rows[(long long)blockIdx.x * ns + s] = s_acc[s];
   const bool last = last_block_arrive(counter, gridDim.x);
   if (last) {
-    for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-      float r = rows[s];
-      for (unsigned int b = 1; b < gridDim.x; ++b) {
-        const float v = rows[(long long)b * ns + s];
-        r = (s >= max_from) ? fmaxf(r, v) : r + v;
+    __shared__ float s_tmp[kLossThreads];
+    if (ns <= (int)blockDim.x) {
+      reduce_rows(rows, (int)gridDim.x, ns, max_from, s_tmp, s_acc);
+    } else {  // rows wider than the block (L = 64 with the widest statistics): plain column walk
+      for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+        float r = rows[s];
+        for (unsigned int b = 1; b < gridDim.x; ++b) {
+          const float v = rows[(long long)b * ns + s];
+          r = (s >= max_from) ? fmaxf(r, v) : r + v;
+        }
+        s_acc[s] = r;
       }
-      s_acc[s] = r;
-      out[s] = r;
+      __syncthreads();
     }
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) out[s] = s_acc[s];
     __syncthreads();
   }
   return last;

@@ -109,10 +109,64 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
                     ((metric_mask & ULTR_METRIC_ERR) ? 1 : 0);
   const int nout = n_met * n_topn * 2;
 
+  const int tid = threadIdx.x;
+  // registers of the short-list path: after the sort, lane (list li, rank r) holds the element ranked r
+  float r_lab = 0.f, r_ilab = 0.f;
+  if (P <= 64) {
+    // Short lists: a list is a group of P lanes inside one wave and never touches LDS.  The bitonic network
+    // exchanges elements between lanes (lane ^ j); 10 exchange steps for P = 16, no barrier.
+    const int r = tid & (P - 1), li = tid / P;
+    const int b = blockIdx.x * LPB + li;
+    float s = -INFINITY, uu = 0.f, lb = 0.f;
+    int id = Lx + r;  // filler
+    if (b < B && r < Lx) {
+      const long long g = (long long)r * B + b;
+      s = scores[g];
+      if (docids && docids[g] == n_rows) s = kPaddingScore;
+      lb = labels ? labels[g] : 0.f;
+      uu = u_pred ? u_pred[(long long)b * Lx + r] : 0.f;
+      id = r;
+    }
+    // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
+    const bool real = id < Lx;
+    const float any_invalid = group_max_rt((real && lb < 0.f) ? 1.f : 0.f, P);
+    if (any_invalid != 0.f) {
+      const float mn = -group_max_rt(real ? -s : -INFINITY, P);
+      if (real && lb < 0.f) {
+        lb = 0.f;
+        s = mn - 1e-6f;
+      }
+    }
+    const float lab_orig = lb;  // label of the document at ORIGINAL position r
+    float il = real ? lb : -INFINITY;
+    const bool want_ideal = (metric_mask & ULTR_METRIC_NDCG) != 0;
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const float ps = __shfl_xor(s, j, 64), pu = __shfl_xor(uu, j, 64);
+        const int pi = __shfl_xor(id, j, 64);
+        const bool lower = (r & j) == 0, first_low = (r & k) == 0;
+        const bool want_first = lower == first_low;  // this lane keeps the element that goes first
+        const bool mine_first = goes_before(s, uu, id, ps, pu, pi, Lx);
+        if (mine_first != want_first) {
+          s = ps; uu = pu; id = pi;
+        }
+        if (want_ideal) {
+          const float pl = __shfl_xor(il, j, 64);
+          // descending labels; on equal values either copy is the same number
+          const bool keep = want_first ? (il >= pl) : (il <= pl);
+          if (!keep) il = pl;
+        }
+      }
+    }
+    // label of the document now ranked r: fetch it from the lane of its original position
+    const int src_lane = (tid & 63) - r + min(id, P - 1);
+    r_lab = __shfl(lab_orig, src_lane, 64);
+    if (id >= Lx) r_lab = 0.f;
+    r_ilab = il;
+  } else {
   load_tile(t, scores, labels, docids, n_rows, u_pred, B, Lx, P, E, LPB);
 
   // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
-  const int tid = threadIdx.x;
   if (tid < LPB) {
     const int base = tid * P;
     bool any_invalid = false;
@@ -134,15 +188,16 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
   __syncthreads();
 
   bitonic_sort_tile(t, P, E, Lx, (metric_mask & ULTR_METRIC_NDCG) != 0);
+  }
 
   if (P <= 64) {
     // short lists: one lane per (list, rank); a list is a P-lane group inside one wave, so sums, maxima and
     // the ERR prefix product are shuffles within the group -- no serial walk, every lane busy
-    const int r = tid & (P - 1), li = tid / P, base = li * P;
+    const int r = tid & (P - 1), li = tid / P;
     const int b = blockIdx.x * LPB + li;
     const bool live = r < Lx;
-    const float lb = live ? t.lab[base + t.idx[tid]] : 0.f;
-    const float il = live ? t.ilab[tid] : 0.f;
+    const float lb = live ? r_lab : 0.f;
+    const float il = live ? r_ilab : 0.f;
     const float gain = live ? exp2f(lb) - 1.f : 0.f, igain = live ? exp2f(il) - 1.f : 0.f;
     const float disc = logf((float)r + 2.f);
     const float gd = gain / disc, igd = igain / disc;
@@ -292,11 +347,9 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
   __syncthreads();
   if (tid < nout) rows[(long long)blockIdx.x * nout + tid] = s_acc[tid];
   if (last_block_arrive(counter, gridDim.x)) {
-    if (tid < nout) {
-      float r = 0.f;
-      for (unsigned int g = 0; g < gridDim.x; ++g) r += rows[(long long)g * nout + tid];
-      if ((tid & 1) == 0 || list_weights) out[tid] = r / (float)B;
-    }
+    __shared__ float s_tmp[kMetThreads];
+    reduce_rows(rows, (int)gridDim.x, nout, 1 << 30, s_tmp, s_acc);
+    if (tid < nout && ((tid & 1) == 0 || list_weights)) out[tid] = s_acc[tid] / (float)B;
   }
 }
 

@@ -17,17 +17,53 @@ __device__ __forceinline__ float eff_scale(const float* denom, float scale_const
   return denom ? scale_const / denom[0] : scale_const;
 }
 
+// A small parameter group (DLA's propensity tower: L+1 floats): norm, clip and update by ONE workgroup.
+struct SmallGroup {
+  float* theta; float* accum; const float* grads; int n; const float* denom;
+  float scale_const, l2, clip_norm, lr; int strategy; float* out_norm;
+};
+__device__ __forceinline__ void clip_adagrad_small(float* theta, float* accum, const float* grads, int n,
+                                                   const float* denom, float scale_const, float l2, float clip_norm,
+                                                   float lr, int strategy, float* out_norm) {
+  __shared__ float red[4];
+  const float sc = eff_scale(denom, scale_const);
+  float ss[1] = {0.f};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float g = grads[i] * sc + l2 * theta[i];
+    ss[0] += g * g;
+  }
+  block_sum<1>(ss, red);
+  const float nrm = sqrtf(ss[0]);
+  if (threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
+  const float f = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float g = (grads[i] * sc + l2 * theta[i]) * f;
+    if (strategy == ULTR_OPT_ADAGRAD) {
+      const float a = accum[i] + g * g;
+      accum[i] = a;
+      theta[i] -= lr * g / sqrtf(a);
+    } else {
+      theta[i] -= lr * g;
+    }
+  }
+}
 __global__ void __launch_bounds__(kOptThreads) gnorm_partial_kernel(const float* __restrict__ theta,
                                                                     const float* __restrict__ grads, long long n,
                                                                     const float* __restrict__ denom, float scale_const,
-                                                                    float l2, float* __restrict__ ws) {
+                                                                    float l2, float* __restrict__ ws, SmallGroup rider) {
+  if (blockIdx.x == gridDim.x - 1 && rider.n > 0) {  // the extra block updates the small group completely
+    clip_adagrad_small(rider.theta, rider.accum, rider.grads, rider.n, rider.denom, rider.scale_const, rider.l2,
+                       rider.clip_norm, rider.lr, rider.strategy, rider.out_norm);
+    return;
+  }
   __shared__ float red[4];
   const float sc = eff_scale(denom, scale_const);
   float acc[1] = {0.f};
   const long long n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(grads);
   const float4* t4 = reinterpret_cast<const float4*>(theta);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+  const long long nb = gridDim.x - (rider.n > 0 ? 1 : 0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += nb * blockDim.x) {
     const float4 g = g4[i];
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (l2 != 0.f) t = t4[i];
@@ -96,46 +132,27 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
   }
 }
 
-// n <= 4096 (DLA's propensity tower: L+1 floats): norm and update in one single-block launch
+// n <= 4096: norm and update in one single-block launch
 __global__ void __launch_bounds__(kOptThreads) clip_adagrad_small_kernel(float* theta, float* accum, const float* grads,
                                                                          int n, const float* denom, float scale_const,
                                                                          float l2, float clip_norm, float lr,
                                                                          int strategy, float* out_norm) {
-  __shared__ float red[4];
-  const float sc = eff_scale(denom, scale_const);
-  float ss[1] = {0.f};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float g = grads[i] * sc + l2 * theta[i];
-    ss[0] += g * g;
-  }
-  block_sum<1>(ss, red);
-  const float nrm = sqrtf(ss[0]);
-  if (threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
-  const float f = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float g = (grads[i] * sc + l2 * theta[i]) * f;
-    if (strategy == ULTR_OPT_ADAGRAD) {
-      const float a = accum[i] + g * g;
-      accum[i] = a;
-      theta[i] -= lr * g / sqrtf(a);
-    } else {
-      theta[i] -= lr * g;
-    }
-  }
+  clip_adagrad_small(theta, accum, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm);
 }
 
 }  // namespace ultr
 
 using namespace ultr;
 
-extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, long long n, const float* denom,
-                                 float scale_const, float l2, float clip_norm, float lr, int strategy,
-                                 float* out_norm, float* ws, void* stream) {
+static int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                             float scale_const, float l2, float clip_norm, float lr, int strategy, float* out_norm,
+                             float* ws, const SmallGroup& rider, void* stream) {
   ULTR_REQUIRE(theta && grads && n > 0, ULTR_EINVAL, "ultr_clip_adagrad: bad argument");
   ULTR_REQUIRE(strategy == ULTR_OPT_ADAGRAD || strategy == ULTR_OPT_SGD, ULTR_EINVAL,
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
   if (n <= 4096) {
+    ULTR_REQUIRE(rider.n == 0, ULTR_EINVAL, "ultr_clip_adagrad2: the main group must have more than 4096 parameters");
     {
       ultr::ProfScope prof_("clip_adagrad_small_kernel", as_stream(stream));
       hipLaunchKernelGGL(clip_adagrad_small_kernel, dim3(1), dim3(kOptThreads), 0, as_stream(stream), theta, acc, grads,
@@ -151,8 +168,8 @@ extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, l
   if (blocks < 1) blocks = 1;
   {
     ultr::ProfScope prof_("gnorm_partial_kernel", as_stream(stream));
-    hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta,
-                     grads, n, denom, scale_const, l2, ws);
+    hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)(blocks + (rider.n > 0 ? 1 : 0))), dim3(kOptThreads), 0,
+                     as_stream(stream), theta, grads, n, denom, scale_const, l2, ws, rider);
   }
   int rc = check_launch("gnorm_partial_kernel");
   if (rc) return rc;
@@ -162,4 +179,22 @@ extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, l
                      grads, n, denom, scale_const, l2, clip_norm, lr, strategy, (int)blocks, out_norm, ws);
   }
   return check_launch("adagrad_apply_kernel");
+}
+
+extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                                 float scale_const, float l2, float clip_norm, float lr, int strategy,
+                                 float* out_norm, float* ws, void* stream) {
+  SmallGroup none{};
+  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, none, stream);
+}
+
+extern "C" int ultr_clip_adagrad2(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                                  float scale_const, float l2, float clip_norm, float lr, int strategy,
+                                  float* out_norm, float* ws, float* theta_s, float* acc_s, const float* grads_s,
+                                  int n_s, const float* denom_s, float scale_const_s, float l2_s, float clip_norm_s,
+                                  float lr_s, float* out_norm_s, void* stream) {
+  ULTR_REQUIRE(theta_s && grads_s && n_s > 0 && n_s <= 4096, ULTR_EINVAL, "ultr_clip_adagrad2: small group needs 1..4096 parameters");
+  ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc_s, ULTR_EINVAL, "ultr_clip_adagrad2: Adagrad needs an accumulator");
+  SmallGroup r{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
+  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, stream);
 }

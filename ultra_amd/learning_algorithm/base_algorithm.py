@@ -347,6 +347,20 @@ class BaseAlgorithm(ABC):
             float(clip_norm), float(lr), self.strategy, _lib.ptr(out_norm), _lib.ptr(self.opt_ws),
             _lib.current_stream()), 'ultr_clip_adagrad')
 
+    def _clip_adagrad2(self, main, small):
+        """Two independent clip + optimiser groups in the launches of one (ultr_clip_adagrad2); each argument is the
+        tuple _clip_adagrad takes.  Falls back to two calls when the main group is too small to host the rider."""
+        if main[3] <= 4096:
+            self._clip_adagrad(*small)
+            self._clip_adagrad(*main)
+            return
+        (th, ac, gr, n, den, sc, l2, clip, lr, out), (ths, acs, grs, ns, dens, scs, l2s, clips, lrs, outs) = main, small
+        _lib.check(_lib.lib().ultr_clip_adagrad2(
+            _lib.ptr(th), _lib.ptr(ac), _lib.ptr(gr), int(n), _lib.ptr(den), float(sc), float(l2), float(clip), float(lr),
+            self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
+            _lib.ptr(ths), _lib.ptr(acs), _lib.ptr(grs), int(ns), _lib.ptr(dens), float(scs), float(l2s), float(clips),
+            float(lrs), _lib.ptr(outs), _lib.current_stream()), 'ultr_clip_adagrad2')
+
     # ---- checkpoint state ---------------------------------------------------------------------------
     def state_dict(self):
         sd = {'params': self.model.params.clone(), 'global_step': torch.tensor(self.global_step.value)}

@@ -83,13 +83,13 @@ class DLA(BaseAlgorithm):
         clip = h.max_gradient_norm if h.max_gradient_norm > 0 else 0.0
         if h.l2_loss > 0:
             local[2:3].copy_((self.model.params[:self.n_params] ** 2).sum().reshape(1) * 0.5)
-        # exam loss -> propensity tower (dla.py:237,241-242,247,250-251)
-        self._clip_adagrad(self.prop_params, self.prop_acc, pg, L + 1, stats[3:4], 1.0, 0.0, clip,
-                           self.propensity_learning_rate.value, local[1:2])
-        # rank loss (+ l2 on the ranker only, :230-234) -> ranking model; clip norm scaled by the loss weight (:243-244)
-        self._clip_adagrad(self.model.params, self.acc, tb['grads'], self.n_total, stats[1:2], 1.0,
-                           h.l2_loss if h.l2_loss > 0 else 0.0, clip * h.ranker_loss_weight,
-                           self.learning_rate.value, local[0:1])
+        # exam loss -> propensity tower (dla.py:237,241-242,247,250-251); rank loss (+ l2 on the ranker only, :230-234)
+        # -> ranking model, clip norm scaled by the loss weight (:243-244).  Two independent clip + Adagrad groups.
+        self._clip_adagrad2(
+            (self.model.params, self.acc, tb['grads'], self.n_total, stats[1:2], 1.0,
+             h.l2_loss if h.l2_loss > 0 else 0.0, clip * h.ranker_loss_weight, self.learning_rate.value, local[0:1]),
+            (self.prop_params, self.prop_acc, pg, L + 1, stats[3:4], 1.0, 0.0, clip,
+             self.propensity_learning_rate.value, local[1:2]))
 
     def _losses(self, stats, local):
         rank = stats[0] / stats[1]
