@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
 
   const int tid = threadIdx.x;
   // registers of the short-list path: after the sort, lane (list li, rank r) holds the element ranked r
-  float r_lab = 0.f, r_ilab = 0.f;
+  float r_lab = 0.f, r_ilab = 0.f, r_w = 1.f;
   if (P <= 64) {
     // Short lists: a list is a group of P lanes inside one wave and never touches LDS.  The bitonic network
     // exchanges elements between lanes (lane ^ j); 10 exchange steps for P = 16, no barrier.
@@ -119,6 +119,8 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
     const int b = blockIdx.x * LPB + li;
     float s = -INFINITY, uu = 0.f, lb = 0.f;
     int id = Lx + r;  // filler
+    // the list weight was written by the kernel right before this one: ask for it now, it is needed last
+    if (b < B && list_weights) r_w = list_weights[b];
     if (b < B && r < Lx) {
       const long long g = (long long)r * B + b;
       s = scores[g];
@@ -228,43 +230,37 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
         if (metric_mask & ULTR_METRIC_ERR) err[q] = gsum(in ? e_term : 0.f);
       }
     }
-    if (r == 0) {
-      float* vals = s_vals + li * nout;
-      for (int o = 0; o < nout; ++o) vals[o] = 0.f;
-      if (b < B) {
-        const float w = list_weights ? list_weights[b] : 1.f;
-        const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
-        int mi = 0;
-        if (metric_mask & ULTR_METRIC_MRR) {
+    // The list's sums are uniform over its P lanes, so lane r forms output o = r (r + P, ...) of the list instead of
+    // lane 0 walking all outputs; the lists of a wave are then added lane-wise (same r), the waves meet in LDS.
+    const float w = r_w;
+    const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
+    const int mi_ndcg = (metric_mask & ULTR_METRIC_MRR) ? 1 : 0;
+    const int mi_err = mi_ndcg + ((metric_mask & ULTR_METRIC_NDCG) ? 1 : 0);
+    float* s_w = s_vals;  // [4 waves][nout]
+    for (int o = r; o < nout; o += P) {
+      const int weighted = o & 1, q = (o >> 1) % n_topn, mi = (o >> 1) / n_topn;
+      float d = 0.f, id = 0.f, er = 0.f;
 #pragma unroll
-          for (int q = 0; q < kMaxTopn; ++q)
-            if (q < n_topn) {
-              vals[(mi * n_topn + q) * 2 + 0] = mrr;
-              vals[(mi * n_topn + q) * 2 + 1] = mrr * w;
-            }
-          ++mi;
+      for (int qq = 0; qq < kMaxTopn; ++qq)
+        if (qq == q) {
+          d = dcg[qq];
+          id = idcg[qq];
+          er = err[qq];
         }
-        if (metric_mask & ULTR_METRIC_NDCG) {
-#pragma unroll
-          for (int q = 0; q < kMaxTopn; ++q)
-            if (q < n_topn) {
-              const float nd = idcg[q] != 0.f ? dcg[q] / idcg[q] : 0.f;
-              const float ndw = (w * idcg[q]) != 0.f ? (w * dcg[q]) / (w * idcg[q]) : 0.f;
-              vals[(mi * n_topn + q) * 2 + 0] = nd * plw_plain;
-              vals[(mi * n_topn + q) * 2 + 1] = ndw * plw_w;
-            }
-          ++mi;
-        }
-        if (metric_mask & ULTR_METRIC_ERR) {
-#pragma unroll
-          for (int q = 0; q < kMaxTopn; ++q)
-            if (q < n_topn) {
-              vals[(mi * n_topn + q) * 2 + 0] = err[q];
-              vals[(mi * n_topn + q) * 2 + 1] = err[q] * w;
-            }
-          ++mi;
-        }
+      float val;
+      if ((metric_mask & ULTR_METRIC_MRR) && mi == 0) {
+        val = weighted ? mrr * w : mrr;
+      } else if ((metric_mask & ULTR_METRIC_NDCG) && mi == mi_ndcg) {
+        const float nd = id != 0.f ? d / id : 0.f;
+        const float ndw = (w * id) != 0.f ? (w * d) / (w * id) : 0.f;
+        val = weighted ? ndw * plw_w : nd * plw_plain;
+      } else {
+        (void)mi_err;
+        val = weighted ? er * w : er;
       }
+      if (b >= B) val = 0.f;
+      for (int off = P; off < 64; off <<= 1) val += __shfl_xor(val, off, 64);  // the other lists of this wave
+      if ((tid & 63) < P) s_w[(tid >> 6) * nout + o] = val;
     }
   } else
   // long lists (evaluation over max_candidate_num): one thread per list walks the sorted list
@@ -339,7 +335,8 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
   __shared__ float s_acc[kMaxOut];
   if (tid < nout) {
     float s = 0.f;
-    for (int l = 0; l < LPB; ++l) s += s_vals[l * nout + tid];
+    const int nrow = P <= 64 ? kMetThreads / 64 : LPB;  // short lists: one row per wave, long lists: one per list
+    for (int l = 0; l < nrow; ++l) s += s_vals[l * nout + tid];
     s_acc[tid] = s;
   }
   unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
