@@ -174,17 +174,17 @@ __device__ __forceinline__ void mma16(const float (&a)[16], const float (&b)[16]
     if ((NCHUNK) > 0) LOAD(0, R0);                        \
     if ((NCHUNK) > 1) LOAD(1, R1);                        \
     if ((NCHUNK) > 0) STORE(R0, 0);                       \
-    __syncthreads();                                      \
+    lds_barrier();                                         \
     for (int c_ = 0; c_ < (NCHUNK); c_ += 2) {            \
       if (c_ + 2 < (NCHUNK)) LOAD(c_ + 2, R0);            \
       COMPUTE(0);                                         \
       if (c_ + 1 < (NCHUNK)) STORE(R1, 1);                \
-      __syncthreads();                                    \
+      lds_barrier();                                       \
       if (c_ + 1 >= (NCHUNK)) break;                      \
       if (c_ + 3 < (NCHUNK)) LOAD(c_ + 3, R1);            \
       COMPUTE(1);                                         \
       if (c_ + 2 < (NCHUNK)) STORE(R0, 0);                \
-      __syncthreads();                                    \
+      lds_barrier();                                       \
     }                                                     \
   } while (0)
 // accumulator register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
@@ -875,11 +875,11 @@ struct WgradArgs {
   float* sslab;            // [nsplit][ldn]
 };
 
-__global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, int bx, int by, int bz) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int wr = w >> 1, wc = w & 1;
-  const int k0 = blockIdx.y * 64 + wr * 32, n0 = blockIdx.z * 64 + wc * 32;
-  const long long m_begin = (long long)blockIdx.x * p.rows_per_split;
+  const int k0 = by * 64 + wr * 32, n0 = bz * 64 + wc * 32;
+  const long long m_begin = (long long)bx * p.rows_per_split;
   long long m_end = m_begin + p.rows_per_split;
   if (m_end > p.M) m_end = p.M;
   const int nch = (int)((m_end - m_begin + 31) >> 5);
@@ -911,7 +911,7 @@ __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float colsum = 0.f;
-  const bool do_colsum = blockIdx.y == 0 && wr == 0;
+  const bool do_colsum = by == 0 && wr == 0;
   auto compute = [&](Frag& S, int i) {
     const long long mc = m_begin + 32 * (long long)i;
     if (mc + 32 > m_end) {
@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) {
     load(1, S1);
     ULTR_STREAM_GEMM(nch, WG_LOAD, WG_COMPUTE);
   }
-  float* g = p.gslab + (long long)blockIdx.x * p.K * p.ldn;
+  float* g = p.gslab + (long long)bx * p.K * p.ldn;
   const int col = n0 + l31;
   if (col < p.ldn) {
 #pragma unroll
@@ -950,9 +950,11 @@ __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) {
   if (do_colsum) {
     float other;
     const float mine = xor32_partner(colsum, &other);  // the two wave halves hold alternate 16-row groups
-    if (h == 0 && col < p.ldn) p.sslab[(long long)blockIdx.x * p.ldn + col] = mine + other;
+    if (h == 0 && col < p.ldn) p.sslab[(long long)bx * p.ldn + col] = mine + other;
   }
 }
+
+__global__ void __launch_bounds__(kThreads) wgrad_kernel(WgradArgs p) { wgrad_body(p, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // ---------------------------------------------------------------------------------------------
 // dgrad:  dh[m][k] = sum_n dz[m][n] * W[k][n]        tile 32 rows x 128 cols (k)
@@ -965,12 +967,12 @@ struct DgradArgs {
   float* dh;                         // [M][ldk]
 };
 
-__global__ void __launch_bounds__(kThreads) dgrad_kernel(DgradArgs p) {
+__device__ __forceinline__ void dgrad_body(const DgradArgs& p, int bx, int by) {
   __shared__ __attribute__((aligned(16))) float As[2][32 * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][128 * LDK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
-  const long long m0 = (long long)blockIdx.x * 32;
-  const int k0 = blockIdx.y * 128;
+  const long long m0 = (long long)bx * 32;
+  const int k0 = by * 128;
   const int a_row = tid >> 3, a_q = tid & 7;  // A: 32 rows x 8 quads; B: 128 rows x 8 quads = 4 per thread
   struct Regs {
     float4 a, b[4];
@@ -1019,6 +1021,28 @@ __global__ void __launch_bounds__(kThreads) dgrad_kernel(DgradArgs p) {
   for (int r = 0; r < 16; ++r) {
     const long long m = m0 + acc_row(r, h);
     if (m < p.M && col < p.ldk) p.dh[m * p.ldk + col] = acc[r];
+  }
+}
+
+__global__ void __launch_bounds__(kThreads, 2) dgrad_kernel(DgradArgs p) { dgrad_body(p, blockIdx.x, blockIdx.y); }
+
+// wgrad_j and dgrad_j both consume dz_j and nothing of each other: one launch runs the two sets of workgroups side
+// by side (dgrad's come first: they run longer), so the pair costs max(wgrad, dgrad) instead of their sum plus a
+// launch gap.  Both bodies fit 256 registers, i.e. two workgroups per CU, one of each kind where the mix allows.
+struct BwdPairArgs {
+  WgradArgs g;
+  DgradArgs d;
+  int d_gx, d_gy;          // dgrad grid
+  int g_gx, g_gy, g_gz;    // wgrad grid
+};
+__global__ void __launch_bounds__(kThreads, 2) bwd_pair_kernel(BwdPairArgs p) {
+  const int nd = p.d_gx * p.d_gy;
+  int id = blockIdx.x;
+  if (id < nd) {
+    dgrad_body(p.d, id % p.d_gx, id / p.d_gx);
+  } else {
+    id -= nd;
+    wgrad_body(p.g, id % p.g_gx, (id / p.g_gx) % p.g_gy, id / (p.g_gx * p.g_gy));
   }
 }
 
@@ -1243,39 +1267,6 @@ static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st, const c
   return launch_fwd<1, 4, false>(a, st, name);
 }
 
-// ---- fork / join inside the backward pass ------------------------------------------------------
-// wgrad_j depends only on dz_j, not on the dgrad -> row-pass chain that produces dz_{j-1}: it runs on a
-// side stream (a parallel branch when the caller's stream is being captured into a hipGraph), and the
-// finalize kernel joins everything.  Streams and events are created on first use, per device.
-struct SideStreams {
-  hipStream_t side[2];
-  hipEvent_t ready[ULTR_MAX_LAYERS + 1];  // recorded on the caller's stream when dz_j is complete
-  hipEvent_t done[ULTR_MAX_LAYERS + 1];   // recorded on a side stream when wgrad_j is complete
-  bool ok;
-};
-static SideStreams* side_streams() {
-  // Opt-in (ULTR_FORK=1): measured on MI355X, a hipGraph with parallel branches replays ~10 us SLOWER per step at
-  // the headline size than the same kernels in one chain (cross-queue dependencies cost more than these
-  // 10-20 us kernels can win back); it pays only for much larger batches.
-  static const bool enabled = [] { const char* e = getenv("ULTR_FORK"); return e && e[0] == '1'; }();
-  if (!enabled) return nullptr;
-  static SideStreams per_dev[64];
-  static bool made[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStreams& S = per_dev[dev];
-  if (!made[dev]) {
-    made[dev] = true;
-    S.ok = true;
-    for (int i = 0; i < 2; ++i) S.ok = S.ok && hipStreamCreateWithFlags(&S.side[i], hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i <= ULTR_MAX_LAYERS; ++i) {
-      S.ok = S.ok && hipEventCreateWithFlags(&S.ready[i], hipEventDisableTiming) == hipSuccess;
-      S.ok = S.ok && hipEventCreateWithFlags(&S.done[i], hipEventDisableTiming) == hipSuccess;
-    }
-  }
-  return S.ok ? &S : nullptr;
-}
-
 static int check_desc(const UltrDnnDesc* d, const char* who) {
   ULTR_REQUIRE(d, ULTR_EINVAL, "%s: null descriptor", who);
   ULTR_REQUIRE(d->n_layers >= 1 && d->n_layers <= ULTR_MAX_LAYERS, ULTR_ELIMIT, "%s: n_layers=%d not in [1,%d]", who,
@@ -1428,56 +1419,50 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
     rc = check_launch("bwd_out_kernel");
     if (rc) return rc;
   }
-  // fork / join: see side_streams().  With per-kernel timing on everything stays on the caller's stream.
-  SideStreams* SS = ultr::g_profile_on ? nullptr : side_streams();
-  unsigned pending = 0;  // layers whose wgrad is still running on a side stream
-#define ULTR_HIP_OK(call)                                                        \
-  do {                                                                           \
-    if ((call) != hipSuccess) {                                                  \
-      set_error("ultr_dnn_backward: %s failed", #call);                          \
-      return ULTR_EHIP;                                                          \
-    }                                                                            \
-  } while (0)
+  // Per layer: wgrad_j, dgrad_j, then the row pass that turns dh into dz_{j-1}.  ULTR_BWD_PAIR=1 runs the two GEMMs
+  // side by side in one launch (bwd_pair_kernel); measured at M = 2560 the pair costs the SUM of its parts (33.7 us
+  // against 17.4 + 16.6), i.e. these kernels are bound by a shared resource -- the memory side feeding just-written
+  // data -- not by latency, so the separate launches stay the default.
+  static const bool pair = [] { const char* e = getenv("ULTR_BWD_PAIR"); return e && e[0] == '1'; }();
   for (int j = H - 1; j >= 0; --j) {
     WgradArgs g{};
     g.xhat = ws + L.xhat[j]; g.ldx = round4(L.K[j]);
     g.dz = ws + L.dz[cur]; g.ldn = L.ldn[j]; g.N = L.N[j];
     g.K = L.K[j]; g.M = M; g.rows_per_split = L.rows_per_split[j];
     g.gslab = ws + L.gslab[j]; g.sslab = ws + L.sslab[j];
-    hipStream_t wst = st;
-    if (SS && j > 0) {  // layer 0's wgrad is the tail of the critical path itself
-      wst = SS->side[j & 1];
-      ULTR_HIP_OK(hipEventRecord(SS->ready[j], st));
-      ULTR_HIP_OK(hipStreamWaitEvent(wst, SS->ready[j], 0));
-    }
-    {
-      ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_kernel/K%dN%d", L.K[j], L.N[j]) : "wgrad_kernel", wst);
-      hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)L.nsplit[j], (unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64)),
-                       dim3(kThreads), 0, wst, g);
-    }
-    rc = check_launch("wgrad_kernel");
-    if (rc) return rc;
-    if (wst != st) {
-      ULTR_HIP_OK(hipEventRecord(SS->done[j], wst));
-      pending |= 1u << j;
+    const dim3 ggrid((unsigned)L.nsplit[j], (unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64));
+    if (j == 0 || !pair) {
+      {
+        ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_kernel/K%dN%d", L.K[j], L.N[j]) : "wgrad_kernel", st);
+        hipLaunchKernelGGL(wgrad_kernel, ggrid, dim3(kThreads), 0, st, g);
+      }
+      rc = check_launch("wgrad_kernel");
+      if (rc) return rc;
     }
     if (j > 0) {
       const int nxt = (cur + 1) % 3;
-      if (j + 2 < H && (pending & (1u << (j + 2)))) {  // dz_{j+2} lives in the buffer dgrad_j is about to overwrite
-        ULTR_HIP_OK(hipStreamWaitEvent(st, SS->done[j + 2], 0));
-        pending &= ~(1u << (j + 2));
-      }
       DgradArgs d{};
       d.dz = ws + L.dz[cur]; d.ldn = L.ldn[j]; d.N = L.N[j];
       d.W = params + desc->off_W[j];
       d.K = L.K[j]; d.ldk = L.ldn[j - 1]; d.M = M;
       d.dh = ws + L.dz[nxt];
-      {
-        ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("dgrad_kernel/K%dN%d", L.K[j], L.N[j]) : "dgrad_kernel", st);
-        hipLaunchKernelGGL(dgrad_kernel, dim3((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128)), dim3(kThreads), 0,
-                         st, d);
+      const dim3 dgrid((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128));
+      if (pair) {
+        BwdPairArgs bp{g, d, (int)dgrid.x, (int)dgrid.y, (int)ggrid.x, (int)ggrid.y, (int)ggrid.z};
+        const long long nblk = (long long)dgrid.x * dgrid.y + (long long)ggrid.x * ggrid.y * ggrid.z;
+        ULTR_REQUIRE(nblk < 2147483647ll, ULTR_ELIMIT, "ultr_dnn_backward: grid too large");
+        {
+          ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("bwd_pair_kernel/K%dN%d", L.K[j], 2 * L.N[j]) : "bwd_pair_kernel", st);
+          hipLaunchKernelGGL(bwd_pair_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, st, bp);
+        }
+        rc = check_launch("bwd_pair_kernel");
+      } else {
+        {
+          ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("dgrad_kernel/K%dN%d", L.K[j], L.N[j]) : "dgrad_kernel", st);
+          hipLaunchKernelGGL(dgrad_kernel, dgrid, dim3(kThreads), 0, st, d);
+        }
+        rc = check_launch("dgrad_kernel");
       }
-      rc = check_launch("dgrad_kernel");
       if (rc) return rc;
       RowpassArgs r{};
       r.dh = ws + L.dz[nxt]; r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
@@ -1495,9 +1480,6 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       cur = nxt;
     }
   }
-  for (int j = 0; j < H; ++j)
-    if (pending & (1u << j)) ULTR_HIP_OK(hipStreamWaitEvent(st, SS->done[j], 0));
-#undef ULTR_HIP_OK
   FinalizeArgs f{};
   f.H = H;
   int start = 0;
