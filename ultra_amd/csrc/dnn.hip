@@ -22,6 +22,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+// No implicit FMA contraction in this file: the compiler contracts a*b+c differently in different unrolled copies
+// of the same loop body, which made a row's result depend (in the last bit) on its position inside a 32-row block.
+// Every fused multiply-add below is written as fmaf() explicitly, so a row's arithmetic is the same wherever it sits.
+#pragma clang fp contract(off)
+
 namespace ultr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
               const int k = 4 * lane + 256 * q;
               const float d0 = k < Kc ? xv[u][q].x - mean[u] : 0.f, d1 = k + 1 < Kc ? xv[u][q].y - mean[u] : 0.f;
               const float d2 = k + 2 < Kc ? xv[u][q].z - mean[u] : 0.f, d3 = k + 3 < Kc ? xv[u][q].w - mean[u] : 0.f;
-              m2[u] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+              m2[u] = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, m2[u]))));
             }
         }
 #pragma unroll
@@ -425,10 +430,10 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
               xh.y = k + 1 < Kc ? (xv[u][q].y - mu) * rs : 0.f;
               xh.z = k + 2 < Kc ? (xv[u][q].z - mu) * rs : 0.f;
               xh.w = k + 3 < Kc ? (xv[u][q].w - mu) * rs : 0.f;
-              a.x = k < Kc ? xh.x * g.x + bt.x : 0.f;
-              a.y = k + 1 < Kc ? xh.y * g.y + bt.y : 0.f;
-              a.z = k + 2 < Kc ? xh.z * g.z + bt.z : 0.f;
-              a.w = k + 3 < Kc ? xh.w * g.w + bt.w : 0.f;
+              a.x = k < Kc ? fmaf(xh.x, g.x, bt.x) : 0.f;
+              a.y = k + 1 < Kc ? fmaf(xh.y, g.y, bt.y) : 0.f;
+              a.z = k + 2 < Kc ? fmaf(xh.z, g.z, bt.z) : 0.f;
+              a.w = k + 3 < Kc ? fmaf(xh.w, g.w, bt.w) : 0.f;
               *reinterpret_cast<float4*>(s_panel + row * PS + k) = a;
               if (p.xhat_out && blockIdx.y == 0 && m0 + row < p.M && kp0 + k < p.ldxh)
                 *reinterpret_cast<float4*>(p.xhat_out + (m0 + row) * p.ldxh + kp0 + k) = xh;
