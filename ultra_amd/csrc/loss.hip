@@ -280,10 +280,7 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(
   __shared__ float s_tower[4][16];  // pre, logit, logp, pw for the last block's chain rule
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = tid & 15, li = tid >> 4;
-  const int b = blockIdx.x * 16 + li;
-  const bool in_list = r < L, live = in_list && b < B;
-  const long long e = (long long)r * B + (b < B ? b : 0);
-  const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f;
+  const bool in_list = r < L;
   // propensity tower (batch independent; every 16-lane group evaluates it): logit_r = ELU(W[r] + b)
   const float pre = in_list ? prop_params[r] + prop_params[L] : 0.f;
   const float logit = eluf_(pre);
@@ -301,40 +298,50 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(
     s_tower[2][tid] = logp;
     s_tower[3][tid] = pw;
   }
-  // the list's own softmax / relevance weights
-  const float m = group_max<16>(live ? o : -INFINITY);
-  const float ex = live ? expf(o - m) : 0.f;
-  const float se = group_sum<16>(ex);
-  const float mean = group_sum<16>(live ? o : 0.f) / (float)L;
-  const float pl = prob_kind == ULTR_PROB_SOFTMAX ? ex / se : sigmoidf_(o - mean);
-  const float p0 = group_sum<16>(r == 0 ? pl : 0.f);
-  const float rw = live ? clip_w(p0 / pl, max_pw) : 0.f;  // relevance weights (dla.py:159-160)
-  const float wl = live ? (c + 0.0000001f) * pw : 0.f;
-  const float S = group_sum<16>(wl);
-  const float lse = m + logf(se);
-  const float cl = fminf(fmaxf(c, 0.f), 1.f);
-  const float lw = group_sum<16>(live ? pw * cl : 0.f);
-  float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f, col = 0.f;
-  if (live) {
-    if (loss_func == ULTR_LOSS_SOFTMAX) {
-      rank_num = -wl * (o - lse);
-      d_scores[e] = expf(o - lse) * S - wl;
-      const float wle = (c + 0.0000001f) * rw;
-      exam_num = -wle * logp;
-      exam_den = wle;
-      col = wle;  // d exam/d logit_l = softmax(logit)_l * sum_b S'_b - sum_b wle
-      rank_den = r == 0 ? S : 0.f;
-    } else {
-      const float z = fminf(c, 1.f);
-      rank_num = sig_ce(z, o) * pw;
-      d_scores[e] = (sigmoidf_(o) - z) * pw;
-      exam_num = sig_ce(z, logit) * rw;
-      col = (sigmoidf_(logit) - z) * rw;  // d exam/d logit_l directly
-      rank_den = r == 0 ? 1.f : 0.f;
-      exam_den = r == 0 ? 1.f : 0.f;
+  // The grid is capped (ultr_loss_workspace_floats): beyond 16 * gridDim.x lists a block walks several groups
+  // of 16 lists and keeps its per-lane sums in registers, so the number of partial rows stays bounded.
+  float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f, col = 0.f, rw_sum = 0.f;
+  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
+    const long long b = b0 + li;
+    const bool live = in_list && b < B;
+    const long long e = (long long)r * B + (b < B ? b : 0);
+    const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f;
+    // the list's own softmax / relevance weights
+    const float m = group_max<16>(live ? o : -INFINITY);
+    const float ex = live ? expf(o - m) : 0.f;
+    const float se = group_sum<16>(ex);
+    const float mean = group_sum<16>(live ? o : 0.f) / (float)L;
+    const float pl = prob_kind == ULTR_PROB_SOFTMAX ? ex / se : sigmoidf_(o - mean);
+    const float p0 = group_sum<16>(r == 0 ? pl : 0.f);
+    const float rw = live ? clip_w(p0 / pl, max_pw) : 0.f;  // relevance weights (dla.py:159-160)
+    const float wl = live ? (c + 0.0000001f) * pw : 0.f;
+    const float S = group_sum<16>(wl);
+    const float lse = m + logf(se);
+    const float cl = fminf(fmaxf(c, 0.f), 1.f);
+    const float lw = group_sum<16>(live ? pw * cl : 0.f);
+    rw_sum += rw;
+    if (live) {
+      if (loss_func == ULTR_LOSS_SOFTMAX) {
+        rank_num += -wl * (o - lse);
+        d_scores[e] = expf(o - lse) * S - wl;
+        const float wle = (c + 0.0000001f) * rw;
+        exam_num += -wle * logp;
+        exam_den += wle;
+        col += wle;  // d exam/d logit_l = softmax(logit)_l * sum_b S'_b - sum_b wle
+        rank_den += r == 0 ? S : 0.f;
+      } else {
+        const float z = fminf(c, 1.f);
+        rank_num += sig_ce(z, o) * pw;
+        d_scores[e] = (sigmoidf_(o) - z) * pw;
+        exam_num += sig_ce(z, logit) * rw;
+        col += (sigmoidf_(logit) - z) * rw;  // d exam/d logit_l directly
+        rank_den += r == 0 ? 1.f : 0.f;
+        exam_den += r == 0 ? 1.f : 0.f;
+      }
+      if (r == 0 && list_weights) list_weights[b] = lw / (float)L;
     }
-    if (r == 0 && list_weights) list_weights[b] = lw / (float)L;
   }
+  const float rw = rw_sum;
   // batch sums: scalars over the whole wave; per-rank columns over the wave's 4 lists (xor 16, xor 32)
   rank_num = wave_sum(rank_num);
   rank_den = wave_sum(rank_den);
@@ -626,7 +633,7 @@ extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, in
   {
     ultr::ProfScope prof_("dla_loss_kernel", as_stream(stream));
     if (L <= 16)
-      hipLaunchKernelGGL(dla_loss_small_kernel, dim3((unsigned)cdiv(B, 16)), dim3(kLossThreads), 0,
+      hipLaunchKernelGGL(dla_loss_small_kernel, dim3((unsigned)(cdiv(B, 16) < 1024 ? cdiv(B, 16) : 1024)), dim3(kLossThreads), 0,
                          as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
                          max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
     else

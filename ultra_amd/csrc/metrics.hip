@@ -13,6 +13,7 @@ namespace ultr {
 constexpr int kMetThreads = 256;
 constexpr int kMaxTopn = 8;
 constexpr int kMaxOut = 3 * kMaxTopn * 2;
+constexpr int kMetMaxBlocks = 1024;  // cap on the grid of the short-list path (a block then walks several list groups)
 constexpr float kPaddingScore = -100000.f;  // BaseAlgorithm.PADDING_SCORE (base_algorithm.py:25)
 
 struct SortTile {
@@ -113,58 +114,144 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
   // registers of the short-list path: after the sort, lane (list li, rank r) holds the element ranked r
   float r_lab = 0.f, r_ilab = 0.f, r_w = 1.f;
   if (P <= 64) {
-    // Short lists: a list is a group of P lanes inside one wave and never touches LDS.  The bitonic network
-    // exchanges elements between lanes (lane ^ j); 10 exchange steps for P = 16, no barrier.
+    // Short lists: a list is a group of P lanes inside one wave and never touches LDS.  The grid is capped
+    // (kMetMaxBlocks): beyond that a block walks several groups of LPB lists and keeps its outputs in registers,
+    // so the number of partial rows the last block has to add stays bounded.
     const int r = tid & (P - 1), li = tid / P;
-    const int b = blockIdx.x * LPB + li;
-    float s = -INFINITY, uu = 0.f, lb = 0.f;
-    int id = Lx + r;  // filler
-    // the list weight was written by the kernel right before this one: ask for it now, it is needed last
-    if (b < B && list_weights) r_w = list_weights[b];
-    if (b < B && r < Lx) {
-      const long long g = (long long)r * B + b;
-      s = scores[g];
-      if (docids && docids[g] == n_rows) s = kPaddingScore;
-      lb = labels ? labels[g] : 0.f;
-      uu = u_pred ? u_pred[(long long)b * Lx + r] : 0.f;
-      id = r;
-    }
-    // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
-    const bool real = id < Lx;
-    const float any_invalid = group_max_rt((real && lb < 0.f) ? 1.f : 0.f, P);
-    if (any_invalid != 0.f) {
-      const float mn = -group_max_rt(real ? -s : -INFINITY, P);
-      if (real && lb < 0.f) {
-        lb = 0.f;
-        s = mn - 1e-6f;
+    constexpr int kAccSlots = kMaxOut / 2;  // outputs per lane: nout / P <= 48 / 2
+    float vacc[kAccSlots];
+#pragma unroll
+    for (int j = 0; j < kAccSlots; ++j) vacc[j] = 0.f;
+    for (long long b0 = (long long)blockIdx.x * LPB; b0 < B; b0 += (long long)gridDim.x * LPB) {
+      const long long b = b0 + li;
+      // the bitonic network exchanges elements between lanes (lane ^ j); 10 exchange steps for P = 16, no barrier
+      float s = -INFINITY, uu = 0.f, lb = 0.f;
+      int id = Lx + r;  // filler
+      // the list weight was written by the kernel right before this one: ask for it now, it is needed last
+      if (b < B && list_weights) r_w = list_weights[b];
+      if (b < B && r < Lx) {
+        const long long g = (long long)r * B + b;
+        s = scores[g];
+        if (docids && docids[g] == n_rows) s = kPaddingScore;
+        lb = labels ? labels[g] : 0.f;
+        uu = u_pred ? u_pred[(long long)b * Lx + r] : 0.f;
+        id = r;
       }
-    }
-    const float lab_orig = lb;  // label of the document at ORIGINAL position r
-    float il = real ? lb : -INFINITY;
-    const bool want_ideal = (metric_mask & ULTR_METRIC_NDCG) != 0;
-    for (int k = 2; k <= P; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        const float ps = __shfl_xor(s, j, 64), pu = __shfl_xor(uu, j, 64);
-        const int pi = __shfl_xor(id, j, 64);
-        const bool lower = (r & j) == 0, first_low = (r & k) == 0;
-        const bool want_first = lower == first_low;  // this lane keeps the element that goes first
-        const bool mine_first = goes_before(s, uu, id, ps, pu, pi, Lx);
-        if (mine_first != want_first) {
-          s = ps; uu = pu; id = pi;
-        }
-        if (want_ideal) {
-          const float pl = __shfl_xor(il, j, 64);
-          // descending labels; on equal values either copy is the same number
-          const bool keep = want_first ? (il >= pl) : (il <= pl);
-          if (!keep) il = pl;
+      // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
+      const bool real = id < Lx;
+      const float any_invalid = group_max_rt((real && lb < 0.f) ? 1.f : 0.f, P);
+      if (any_invalid != 0.f) {
+        const float mn = -group_max_rt(real ? -s : -INFINITY, P);
+        if (real && lb < 0.f) {
+          lb = 0.f;
+          s = mn - 1e-6f;
         }
       }
+      const float lab_orig = lb;  // label of the document at ORIGINAL position r
+      float il = real ? lb : -INFINITY;
+      const bool want_ideal = (metric_mask & ULTR_METRIC_NDCG) != 0;
+      for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const float ps = __shfl_xor(s, j, 64), pu = __shfl_xor(uu, j, 64);
+          const int pi = __shfl_xor(id, j, 64);
+          const bool lower = (r & j) == 0, first_low = (r & k) == 0;
+          const bool want_first = lower == first_low;  // this lane keeps the element that goes first
+          const bool mine_first = goes_before(s, uu, id, ps, pu, pi, Lx);
+          if (mine_first != want_first) {
+            s = ps; uu = pu; id = pi;
+          }
+          if (want_ideal) {
+            const float pl = __shfl_xor(il, j, 64);
+            // descending labels; on equal values either copy is the same number
+            const bool keep = want_first ? (il >= pl) : (il <= pl);
+            if (!keep) il = pl;
+          }
+        }
+      }
+      // label of the document now ranked r: fetch it from the lane of its original position
+      const int src_lane = (tid & 63) - r + min(id, P - 1);
+      r_lab = __shfl(lab_orig, src_lane, 64);
+      if (id >= Lx) r_lab = 0.f;
+      r_ilab = il;
+      // short lists: one lane per (list, rank); a list is a P-lane group inside one wave, so sums, maxima and
+      // the ERR prefix product are shuffles within the group -- no serial walk, every lane busy
+      const bool live = r < Lx;
+      const float lbr = live ? r_lab : 0.f;
+      const float ilr = live ? r_ilab : 0.f;
+      const float gain = live ? exp2f(lbr) - 1.f : 0.f, igain = live ? exp2f(ilr) - 1.f : 0.f;
+      const float disc = logf((float)r + 2.f);
+      const float gd = gain / disc, igd = igain / disc;
+      auto gsum = [&](float v) { return group_sum_rt(v, P); };
+      const float rel_sum = gsum(gain);
+      float mrr = (live && lbr >= 1.f) ? 1.f / (float)(r + 1) : 0.f;
+      mrr = group_max_rt(mrr, P);
+      float e_term = 0.f;
+      if (metric_mask & ULTR_METRIC_ERR) {
+        const float rel = gain / powf(2.f, max_label);  // metrics.py:312-313
+        float cum = live ? 1.f - rel : 1.f;             // inclusive prefix product within the group
+        for (int o = 1; o < P; o <<= 1) {
+          const float up = __shfl_up(cum, o, 64);
+          if (r >= o) cum *= up;
+        }
+        e_term = live ? rel * (cum / (1.f - rel)) / (float)(r + 1) : 0.f;  // cumprod/(1-rel) (:314)
+      }
+      float dcg[kMaxTopn], idcg[kMaxTopn], err[kMaxTopn];
+  #pragma unroll
+      for (int q = 0; q < kMaxTopn; ++q) {
+        dcg[q] = idcg[q] = err[q] = 0.f;
+        if (q < n_topn) {
+          const bool in = r < topn[q];
+          if (metric_mask & ULTR_METRIC_NDCG) {
+            dcg[q] = gsum(in ? gd : 0.f);
+            idcg[q] = gsum(in ? igd : 0.f);
+          }
+          if (metric_mask & ULTR_METRIC_ERR) err[q] = gsum(in ? e_term : 0.f);
+        }
+      }
+      // The list's sums are uniform over its P lanes, so lane r forms output o = r (r + P, ...) of the list instead of
+      // lane 0 walking all outputs; the lists of a wave are then added lane-wise (same r), the waves meet in LDS.
+      const float w = r_w;
+      const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
+      const int mi_ndcg = (metric_mask & ULTR_METRIC_MRR) ? 1 : 0;
+      const int mi_err = mi_ndcg + ((metric_mask & ULTR_METRIC_NDCG) ? 1 : 0);
+      for (int o = r; o < nout; o += P) {
+        const int weighted = o & 1, q = (o >> 1) % n_topn, mi = (o >> 1) / n_topn;
+        float d = 0.f, idn = 0.f, er = 0.f;
+  #pragma unroll
+        for (int qq = 0; qq < kMaxTopn; ++qq)
+          if (qq == q) {
+            d = dcg[qq];
+            idn = idcg[qq];
+            er = err[qq];
+          }
+        float val;
+        if ((metric_mask & ULTR_METRIC_MRR) && mi == 0) {
+          val = weighted ? mrr * w : mrr;
+        } else if ((metric_mask & ULTR_METRIC_NDCG) && mi == mi_ndcg) {
+          const float nd = idn != 0.f ? d / idn : 0.f;
+          const float ndw = (w * idn) != 0.f ? (w * d) / (w * idn) : 0.f;
+          val = weighted ? ndw * plw_w : nd * plw_plain;
+        } else {
+          (void)mi_err;
+          val = weighted ? er * w : er;
+        }
+        if (b >= B) val = 0.f;
+        const int slot = (o - r) / P;
+#pragma unroll
+        for (int j = 0; j < kAccSlots; ++j)
+          if (j == slot) vacc[j] += val;
+      }
     }
-    // label of the document now ranked r: fetch it from the lane of its original position
-    const int src_lane = (tid & 63) - r + min(id, P - 1);
-    r_lab = __shfl(lab_orig, src_lane, 64);
-    if (id >= Lx) r_lab = 0.f;
-    r_ilab = il;
+    float* s_w = s_vals;  // [4 waves][nout]
+    for (int o = r; o < nout; o += P) {
+      float val = 0.f;
+      const int slot = (o - r) / P;
+#pragma unroll
+      for (int j = 0; j < kAccSlots; ++j)
+        if (j == slot) val = vacc[j];
+      for (int off = P; off < 64; off <<= 1) val += __shfl_xor(val, off, 64);  // the other lists of this wave
+      if ((tid & 63) < P) s_w[(tid >> 6) * nout + o] = val;
+    }
   } else {
   load_tile(t, scores, labels, docids, n_rows, u_pred, B, Lx, P, E, LPB);
 
@@ -190,79 +277,6 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
   __syncthreads();
 
   bitonic_sort_tile(t, P, E, Lx, (metric_mask & ULTR_METRIC_NDCG) != 0);
-  }
-
-  if (P <= 64) {
-    // short lists: one lane per (list, rank); a list is a P-lane group inside one wave, so sums, maxima and
-    // the ERR prefix product are shuffles within the group -- no serial walk, every lane busy
-    const int r = tid & (P - 1), li = tid / P;
-    const int b = blockIdx.x * LPB + li;
-    const bool live = r < Lx;
-    const float lb = live ? r_lab : 0.f;
-    const float il = live ? r_ilab : 0.f;
-    const float gain = live ? exp2f(lb) - 1.f : 0.f, igain = live ? exp2f(il) - 1.f : 0.f;
-    const float disc = logf((float)r + 2.f);
-    const float gd = gain / disc, igd = igain / disc;
-    auto gsum = [&](float v) { return group_sum_rt(v, P); };
-    const float rel_sum = gsum(gain);
-    float mrr = (live && lb >= 1.f) ? 1.f / (float)(r + 1) : 0.f;
-    mrr = group_max_rt(mrr, P);
-    float e_term = 0.f;
-    if (metric_mask & ULTR_METRIC_ERR) {
-      const float rel = gain / powf(2.f, max_label);  // metrics.py:312-313
-      float cum = live ? 1.f - rel : 1.f;             // inclusive prefix product within the group
-      for (int o = 1; o < P; o <<= 1) {
-        const float up = __shfl_up(cum, o, 64);
-        if (r >= o) cum *= up;
-      }
-      e_term = live ? rel * (cum / (1.f - rel)) / (float)(r + 1) : 0.f;  // cumprod/(1-rel) (:314)
-    }
-    float dcg[kMaxTopn], idcg[kMaxTopn], err[kMaxTopn];
-#pragma unroll
-    for (int q = 0; q < kMaxTopn; ++q) {
-      dcg[q] = idcg[q] = err[q] = 0.f;
-      if (q < n_topn) {
-        const bool in = r < topn[q];
-        if (metric_mask & ULTR_METRIC_NDCG) {
-          dcg[q] = gsum(in ? gd : 0.f);
-          idcg[q] = gsum(in ? igd : 0.f);
-        }
-        if (metric_mask & ULTR_METRIC_ERR) err[q] = gsum(in ? e_term : 0.f);
-      }
-    }
-    // The list's sums are uniform over its P lanes, so lane r forms output o = r (r + P, ...) of the list instead of
-    // lane 0 walking all outputs; the lists of a wave are then added lane-wise (same r), the waves meet in LDS.
-    const float w = r_w;
-    const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
-    const int mi_ndcg = (metric_mask & ULTR_METRIC_MRR) ? 1 : 0;
-    const int mi_err = mi_ndcg + ((metric_mask & ULTR_METRIC_NDCG) ? 1 : 0);
-    float* s_w = s_vals;  // [4 waves][nout]
-    for (int o = r; o < nout; o += P) {
-      const int weighted = o & 1, q = (o >> 1) % n_topn, mi = (o >> 1) / n_topn;
-      float d = 0.f, id = 0.f, er = 0.f;
-#pragma unroll
-      for (int qq = 0; qq < kMaxTopn; ++qq)
-        if (qq == q) {
-          d = dcg[qq];
-          id = idcg[qq];
-          er = err[qq];
-        }
-      float val;
-      if ((metric_mask & ULTR_METRIC_MRR) && mi == 0) {
-        val = weighted ? mrr * w : mrr;
-      } else if ((metric_mask & ULTR_METRIC_NDCG) && mi == mi_ndcg) {
-        const float nd = id != 0.f ? d / id : 0.f;
-        const float ndw = (w * id) != 0.f ? (w * d) / (w * id) : 0.f;
-        val = weighted ? ndw * plw_w : nd * plw_plain;
-      } else {
-        (void)mi_err;
-        val = weighted ? er * w : er;
-      }
-      if (b >= B) val = 0.f;
-      for (int off = P; off < 64; off <<= 1) val += __shfl_xor(val, off, 64);  // the other lists of this wave
-      if ((tid & 63) < P) s_w[(tid >> 6) * nout + o] = val;
-    }
-  } else
   // long lists (evaluation over max_candidate_num): one thread per list walks the sorted list
   if (tid < LPB) {
     const int base = tid * P;
@@ -329,6 +343,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(
         ++mi;
       }
     }
+  }
   }
   __syncthreads();
   // block partial sums in fixed order, then the last block divides by B (reduce_mean over lists)
@@ -417,7 +432,7 @@ extern "C" int ultr_metrics(const float* scores, const float* labels, const int*
   }
   {
     ultr::ProfScope prof_("metrics_kernel", as_stream(stream));
-    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)cdiv(B, LPB)), dim3(kMetThreads), smem, as_stream(stream), scores,
+    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)((P <= 64 && cdiv(B, LPB) > kMetMaxBlocks) ? kMetMaxBlocks : cdiv(B, LPB))), dim3(kMetThreads), smem, as_stream(stream), scores,
                      labels, docids, n_rows, list_weights, u_pred, B, Lx, P, LPB, n_topn, tn[0], tn[1], tn[2], tn[3],
                      tn[4], tn[5], tn[6], tn[7], metric_mask, max_label, out, ws);
   }
