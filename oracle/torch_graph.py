@@ -324,6 +324,29 @@ class TorchReferenceStep(object):
             summary['Loss'] = float(loss.detach().sum())
             lw = (pwt * labels_bl.clamp(0, 1)).mean(1, keepdim=True)
             summary.update(self._train_metrics(labels_bl, train_output, docids, n_rows, lw, u_pred))
+        elif self.algo == 'naive':  # navie_algorithm.py:85-170: the same losses with propensity_weights = None (ones)
+            ones = torch.ones_like(labels_bl)
+            if hp['loss_func'] == 'sigmoid_cross_entropy':
+                loss = sigmoid_loss_on_list(train_output, labels_bl, ones)
+            else:
+                loss = softmax_loss(train_output, labels_bl, ones)
+            if hp['l2_loss'] > 0:
+                l2 = sum((p * p).sum() / 2 for p in rv)
+                summary['L2 Loss'] = float(l2.detach())
+                loss = loss + hp['l2_loss'] * l2
+            g = torch.autograd.grad(loss, rv)
+            if hp['max_gradient_norm'] > 0:
+                g, norm = clip_by_global_norm(list(g), hp['max_gradient_norm'])
+                summary['Gradient Norm'] = float(norm)
+            self.grads = {'ranker': [x.clone() for x in g]}
+            self._apply(rv, g, hp['learning_rate'])
+            pad_removed = remove_padding(docids, train_output.detach(), n_rows)
+            summary.update({'Max_output_score': float(train_output.detach().max()),
+                            'Min_output_score': float(train_output.detach().min()),
+                            'Max_output_score_without_pad': float(pad_removed.max()),
+                            'Min_output_score_without_pad': float(pad_removed.min()),
+                            'Loss': float(loss.detach().sum())})
+            summary.update(self._train_metrics(labels_bl, train_output, docids, n_rows, None, u_pred))
         elif self.algo == 'rem':
             train_output = train_output + self.sigmoid_prob_b
             gamma = torch.sigmoid(train_output)

@@ -158,6 +158,38 @@ def test_ipw_steps_match_reference_graph():
     compare_params(model, ref, 3e-5)
 
 
+@pytest.mark.parametrize('hp,ranker,ranker_hp', [
+    ('', 'DNN', 'hidden_layer_sizes=[64, 32]'),
+    ('loss_func=sigmoid_cross_entropy,l2_loss=0.001', 'DNN', 'hidden_layer_sizes=[64, 32]'),
+    ('', 'Linear', ''),
+    ('grad_strategy=sgd,learning_rate=0.01', 'Linear', 'norm=none')])
+def test_naive_steps_match_reference_graph(hp, ranker, ranker_hp):
+    """NavieAlgorithm (clicks as labels, no debiasing) on the DNN and on the Linear scorer (navie_algorithm.py,
+    Linear.py): same reference graph as IPW with unit propensity weights."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(300, 10, 20, seed=11, pad_frac=0.1)
+    exp = settings('NavieAlgorithm', hp, model_hparams=ranker_hp)
+    exp['ranking_model'] = 'ultra_amd.ranking_model.' + ranker
+    model, feed = make('NavieAlgorithm', data, exp, 128)
+    hpd = dict(kv.split('=') for kv in hp.split(',')) if hp else {}
+    hpd = {k: (v if k in ('loss_func', 'grad_strategy') else float(v)) for k, v in hpd.items()}
+    ref = reference_for('naive', model, 10, hpd, norm='none' if 'norm=none' in ranker_hp else 'layer')
+    if ranker == 'Linear':
+        assert sorted(model.model.model_parameters)[-2:] == ['ranking_model/linear_W_0:0', 'ranking_model/linear_b_0:0']
+    for step in range(3):
+        feed_dict, _ = feed.get_batch(data, True)
+        table, d, c = torch_feed(data, feed_dict[DEVICE_BATCH_KEY])
+        u = tie_uniforms(model, np.random.RandomState(step), 128)
+        loss, _, summary = model.step(None, feed_dict, False)
+        ref_loss, ref_sum = ref.step(table, d, c, u_pred=u)
+        assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+        got = summary.as_dict()
+        assert set(t.replace(' ', '_') for t in ref_sum) | {'Learning_Rate'} == set(got), (sorted(ref_sum), sorted(got))
+        for tag, val in ref_sum.items():
+            assert abs(got[tag.replace(' ', '_')] - val) <= 2e-5 * max(abs(val), 1e-2), tag
+    compare_params(model, ref, 3e-5)
+
+
 def test_rem_steps_match_reference_graph():
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
     data = SyntheticData(300, 10, 20, seed=9)

@@ -98,7 +98,9 @@ def test_find_class_and_settings_names():
     assert find_class('ultra_amd.learning_algorithm.IPWrank').__name__ == 'IPWrank'
     assert find_class('ultra_amd.learning_algorithm.RegressionEM').__name__ == 'RegressionEM'
     assert find_class('ultra_amd.learning_algorithm.PairDebias').__name__ == 'PairDebias'
+    assert find_class('ultra_amd.learning_algorithm.NavieAlgorithm').__name__ == 'NavieAlgorithm'
     assert find_class('ultra_amd.ranking_model.DNN').__name__ == 'DNN'
+    assert find_class('ultra_amd.ranking_model.Linear').__name__ == 'Linear'
     assert find_class('ultra_amd.input_layer.ClickSimulationFeed').__name__ == 'ClickSimulationFeed'
     assert find_class('ultra_amd.input_layer.DirectLabelFeed').__name__ == 'DirectLabelFeed'
     with pytest.raises(ImportError):
