@@ -38,18 +38,23 @@ def per_kernel_mean(path, counter):
     return {k: v[0] / v[1] for k, v in acc.items()}
 
 
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/: take the latest pass, not an earlier one."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
     src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
     dst = os.path.join(ROOT, 'profiles')
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
+    stats = newest(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))
     shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
-    trace = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_trace.csv'))[0]
+    trace = newest(os.path.join(src, 'stats', '*', '*_kernel_trace.csv'))
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_summary.py'), trace], capture_output=True, text=True)
     open(os.path.join(dst, tag + '_kernel_by_grid.txt'), 'w').write(out.stdout)
-    fetch = per_kernel_mean(glob.glob(os.path.join(src, 'fetch', '*', '*_counter_collection.csv'))[0], 'FETCH_SIZE')
-    write = per_kernel_mean(glob.glob(os.path.join(src, 'write', '*', '*_counter_collection.csv'))[0], 'WRITE_SIZE')
+    fetch = per_kernel_mean(newest(os.path.join(src, 'fetch', '*', '*_counter_collection.csv')), 'FETCH_SIZE')
+    write = per_kernel_mean(newest(os.path.join(src, 'write', '*', '*_counter_collection.csv')), 'WRITE_SIZE')
     res = {'unit': 'bytes per launch', 'correction': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests as 64 B) + WRITE_SIZE KiB x 1024',
            'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_profile --graph 0',
            'kernels': {}}
