@@ -152,7 +152,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='mslr10k', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=256, help='query lists per step per GPU')
-    ap.add_argument('--graph', type=int, default=-1, help='replay the step as one hipGraph (default: on for 1 GPU)')
+    ap.add_argument('--graph', type=int, default=-1,
+                    help='0: eager launches; 1: the whole step as one hipGraph (single GPU only); 2: two hipGraphs '
+                         '(before / after the collective) with the RCCL all-reduce issued between them.  Default: 1 on '
+                         'one GPU, 2 on several')
+    ap.add_argument('--force_collective', action='store_true',
+                    help='single-GPU rehearsal of the multi-GPU launch path: a 1-rank RCCL group, all-reduce issued anyway')
     ap.add_argument('--algo_hparams', default='')
     ap.add_argument('--cpu_seconds', type=float, default=12.0)
     ap.add_argument('--no_cpu_baseline', action='store_true')
@@ -166,13 +171,29 @@ def main():
     device = torch.device('cuda', local_rank)
     if world > 1:
         torch.distributed.init_process_group('nccl', device_id=device)
+    elif args.force_collective:
+        torch.distributed.init_process_group('nccl', init_method='tcp://127.0.0.1:29577', rank=0, world_size=1,
+                                             device_id=device)
     cfg = CONFIGS[args.config]
     with contextlib.redirect_stdout(sys.stderr):  # the plugin classes print progress lines like the reference does
         data, exp, model, feed = build_world(cfg, args, device)
-    use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 0)
+    use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 2)
+    if use_graph == 1 and (world > 1 or args.force_collective):
+        use_graph = 2  # the collective is never captured
+
+    def collective():
+        if args.force_collective and world == 1:
+            tb = model._train_bufs
+            torch.distributed.all_reduce(tb['bucket'][:tb['n_reduce']])
+        else:
+            model.step_reduce()
 
     def step():
         input_feed, _ = feed.get_batch(data, check_validation=True)
+        if args.force_collective and world == 1:
+            model.step_local(input_feed)
+            collective()
+            return model.step_apply()
         return model.step(None, input_feed, False)
 
     def barrier():
@@ -183,23 +204,61 @@ def main():
     for _ in range(max(args.warmup, 3)):
         last = step()
     barrier()
-    graph = None
+
+    # Launch paths: eager launches (the host enqueues ahead of the GPU), or hipGraph replay.  Which one is faster
+    # depends on the host's enqueue cost against the step's GPU time, so with --graph -1 both are rehearsed for a
+    # few steps and the timed region uses the faster one; "launch" in the output names it.
+    paths = {'eager': step}
+    last_of = {}
     if use_graph:
         try:
             model.enable_graph_replay(True)
             step()
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                last = step()
-            graph.replay()
+            if use_graph == 1:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    last_of['hipGraph replay'] = step()
+                paths['hipGraph replay'] = graph.replay
+            else:
+                # feed + forward + loss + metrics + backward | all-reduce (eager, RCCL's own stream) | update + publish
+                graph, graph_apply = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    input_feed, _ = feed.get_batch(data, check_validation=True)
+                    model.step_local(input_feed)
+                with torch.cuda.graph(graph_apply):
+                    last_of['two hipGraphs around one RCCL all-reduce'] = model.step_apply()
+
+                def run_split():
+                    graph.replay()
+                    collective()
+                    graph_apply.replay()
+                paths['two hipGraphs around one RCCL all-reduce'] = run_split
+            list(paths.values())[-1]()
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001 - report and time the eager launch path instead
             log('hipGraph capture failed (%s: %s); timing eager launches' % (type(e).__name__, e))
-            graph = None
+            paths = {'eager': step}
             model.enable_graph_replay(False)
             torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
+    if args.graph >= 0 and len(paths) > 1:
+        del paths['eager']                       # an explicit --graph 1/2 is honoured
+    launch = list(paths)[0]
+    if len(paths) > 1:
+        trial = {}
+        for name, fn in paths.items():
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                fn()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)  # every rank picks the same path
+            trial[name] = float(t.item())
+            log('  launch path %-45s %8.1f us/step over 30 steps' % (name, trial[name] / 30 * 1e6))
+        launch = min(trial, key=trial.get)
+    run = paths[launch]
 
     barrier()
     t0 = time.perf_counter()
@@ -207,8 +266,7 @@ def main():
         r = run()
     barrier()
     dt = time.perf_counter() - t0
-    if graph is None:
-        last = r
+    last = r if launch == 'eager' else last_of[launch]
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -265,7 +323,7 @@ def main():
                                    args.config, cfg['F'], cfg['L'], args.batch, cfg['algo'],
                                    'PBM' if 'pbm' in cfg['click'] else 'cascade', cfg['Q']),
                    'global_batch': args.batch * world, 'list_size': cfg['L'], 'parallelism': 'dp%d' % world,
-                   'launch': 'hipGraph replay' if graph is not None else 'eager',
+                   'launch': launch,
                    'train_gflop_per_step_per_gpu': round(train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9, 3)},
         'final_loss': loss_value,
     }
@@ -275,7 +333,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(cfg, args, data, model)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -275,6 +275,14 @@ class BaseAlgorithm(ABC):
     WEIGHTED_METRICS = True
 
     def _train_step(self, input_feed):
+        self.step_local(input_feed)
+        self.step_reduce()
+        return self.step_apply()
+
+    # The three phases of a training step, callable one by one so that a data-parallel driver can replay the two
+    # compute phases as hipGraphs and issue the collective between them (bench.py does; RCCL stays outside capture).
+    def step_local(self, input_feed):
+        """Everything before the collective: scores, loss + d_scores, in-step metrics, flat un-normalised gradient."""
         L = self.rank_list_size
         batch = self._to_device_batch(input_feed, L)
         tb = self._train_buffers(batch.B)
@@ -294,7 +302,15 @@ class BaseAlgorithm(ABC):
         else:
             self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS)
             self.model.backward(tb['d_scores'], tb['grads'])
-        self._all_reduce(tb)                                   # DP: one collective per step
+        self._pending = (tb, batch)
+
+    def step_reduce(self):
+        """DP: the one collective of the step (sum of [grads | statistics | metrics] over ranks)."""
+        self._all_reduce(self._pending[0])
+
+    def step_apply(self):
+        """EM state, clip + Adagrad, publish; -> (loss, None, summary)."""
+        tb, batch = self._pending
         self._update(tb, batch)                                # EM state, clip + Adagrad
         fetch = self._publish(tb)
         self.global_step.value += 1
