@@ -654,6 +654,274 @@ __global__ void __launch_bounds__(kThreads) fwd_out_kernel(OutArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward chain: ALL layers of the scorer for 16 rows in one workgroup.
+//
+// A row's path through the network (gather -> LN -> GEMM -> bias -> act -> LN -> ... -> score) never needs another
+// row, and 16 rows of every hidden width fit in LDS, so the per-layer kernels above -- each of which starts on a
+// cold L2 and reads what the previous one has just written, the slow path of this memory system -- collapse into
+// one launch whose activations never leave the CU between layers.  What still goes to memory is what the backward
+// pass wants back: act_j, xhat_j, the row statistics.
+//
+//   * 8 waves, M / 16 workgroups (160 at the headline batch).  v_mfma_f32_16x16x4_f32; a wave owns a UNIT of 64
+//     output columns = four 16x16 accumulators.  Column c of the unit sits in accumulator c % 4, slot c / 4, so one
+//     float4 weight load per lane feeds four MFMAs and a lane ends up with 4 rows x 4 CONSECUTIVE columns
+//     (float4 stores); along the contraction a lane's float4 of the LDS panel feeds four MFMA steps (step s of
+//     16-chunk c contracts k = 16 c + 4 (lane / 16) + s on both operands).
+//   * layers narrower than 8 units split the contraction over the idle waves (8 / units slices) and meet in LDS.
+//   * weights stream from L2 (they are the same for every workgroup), three 16-deep chunks ahead, and the stream
+//     of a layer starts before its input rows are normalised.
+// ---------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kChainThreads = 512, kChainRows = 16, kChainExch = 7 * 1024;
+
+struct ChainArgs {
+  const float* table; int ldx; const int* docids; int n_rows; const float* row_stats;
+  int has_ln; float eps; int activation; int H; long long M;
+  const float* W[ULTR_MAX_LAYERS]; const float* bias[ULTR_MAX_LAYERS];
+  const float* gamma[ULTR_MAX_LAYERS]; const float* beta[ULTR_MAX_LAYERS];
+  int K[ULTR_MAX_LAYERS], N[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS];
+  float* act_out[ULTR_MAX_LAYERS]; float* xhat_out[ULTR_MAX_LAYERS]; float* stat_out[ULTR_MAX_LAYERS];
+  float* scores;
+  int PS;          // LDS panel row stride in floats, == 4 (mod 32)
+  int buf_floats;  // each of the two LDS buffers
+};
+
+__device__ __forceinline__ float4 act4_rt(int kind, float4 z) {
+  switch (kind) {
+#define ULTR_ACT4(A) case A: return make_float4(act_fwd(A, z.x), act_fwd(A, z.y), act_fwd(A, z.z), act_fwd(A, z.w));
+    ULTR_ACT4(ULTR_ACT_ELU)
+    ULTR_ACT4(ULTR_ACT_RELU)
+    ULTR_ACT4(ULTR_ACT_SELU)
+    ULTR_ACT4(ULTR_ACT_TANH)
+    default: return make_float4(act_fwd(ULTR_ACT_SIGMOID, z.x), act_fwd(ULTR_ACT_SIGMOID, z.y),
+                                act_fwd(ULTR_ACT_SIGMOID, z.z), act_fwd(ULTR_ACT_SIGMOID, z.w));
+#undef ULTR_ACT4
+  }
+}
+
+__global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nn = lane & 15, kk = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * kChainRows;
+  const int PS = p.PS;
+  float* cur = smem;
+  float* nxt = smem + p.buf_floats;
+  struct Frag { float4 b[4]; } S0, S1, S2;
+  ULTR_STAMP(5, 0);
+
+  for (int j = 0; j <= p.H; ++j) {
+    const int K = p.K[j], K16 = (K + 15) & ~15;
+    const bool last = j == p.H;
+    // ---- geometry of this layer's GEMM (unused for the output layer)
+    const int N = last ? 1 : p.N[j], ldn = last ? 4 : p.ldn[j];
+    const int U = (N + 63) >> 6;
+    int Up = 1;
+    while (Up < U && Up < 8) Up <<= 1;
+    const int KS = U >= 8 ? 1 : 8 / Up;
+    const int ks = U >= 8 ? 0 : w / Up;
+    const int u_first = U >= 8 ? w : w % Up;
+    const int nchunks = K16 >> 4, cps = (nchunks + KS - 1) / KS;
+    const int c_begin = ks * cps, c_end = min(c_begin + cps, nchunks);
+    const int nch = max(c_end - c_begin, 0), c_last = max(c_end - 1, 0);
+    const float* __restrict__ Wj = p.W[j];
+    int colc = min(64 * u_first + 4 * nn, ldn - 4);
+#define CH_LOAD(i, S)                                                                              \
+  do {                                                                                             \
+    const int k0_ = 16 * min(c_begin + (i), c_last) + 4 * kk;                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                               \
+      S.b[s_] = *reinterpret_cast<const float4*>(Wj + (size_t)min(k0_ + s_, K - 1) * ldn + colc);  \
+  } while (0)
+    if (!last && u_first < U) {  // the weight stream starts before the rows are ready
+      CH_LOAD(0, S0);
+      CH_LOAD(1, S1);
+    }
+
+    // ---- input stage: wave w owns rows 2w and 2w+1; lanes run along the row (float4 each)
+    {
+      const int nq = (K16 + 255) >> 8;  // <= 4 (widths <= 1024)
+      float4 xv[2][4];
+      float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+      bool pad[2] = {false, false};
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int row = 2 * w + r2;
+        const long long m = min(m0 + row, p.M - 1);
+        if (j == 0) {
+          const int d = p.docids[m];
+          pad[r2] = d >= p.n_rows;
+          const float* src = p.table + (long long)(pad[r2] ? 0 : d) * p.ldx;
+          if (p.has_ln) {
+            mean[r2] = p.row_stats[2 * (long long)d];
+            rstd[r2] = p.row_stats[2 * (long long)d + 1];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nq) xv[r2][q] = *reinterpret_cast<const float4*>(src + min(4 * lane + 256 * q, p.ldx - 4));
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nq) xv[r2][q] = *reinterpret_cast<const float4*>(cur + row * PS + min(4 * lane + 256 * q, K16 - 4));
+        }
+      }
+      if (j > 0 && p.has_ln) {  // two-pass statistics of the two rows, interleaved
+        float sm[2], m2[2];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          sm[r2] = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              sm[r2] += (k < K ? xv[r2][q].x : 0.f) + (k + 1 < K ? xv[r2][q].y : 0.f) + (k + 2 < K ? xv[r2][q].z : 0.f) +
+                        (k + 3 < K ? xv[r2][q].w : 0.f);
+            }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) mean[r2] = wave_sum(sm[r2]) / (float)K;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          m2[r2] = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              const float d0 = k < K ? xv[r2][q].x - mean[r2] : 0.f, d1 = k + 1 < K ? xv[r2][q].y - mean[r2] : 0.f;
+              const float d2 = k + 2 < K ? xv[r2][q].z - mean[r2] : 0.f, d3 = k + 3 < K ? xv[r2][q].w - mean[r2] : 0.f;
+              m2[r2] = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, m2[r2]))));
+            }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          rstd[r2] = 1.f / sqrtf(wave_sum(m2[r2]) / (float)K + p.eps);  // biased variance (keras LayerNormalization)
+          const long long m = m0 + 2 * w + r2;
+          if (lane == 0 && m < p.M) *reinterpret_cast<float2*>(p.stat_out[j] + 2 * m) = make_float2(mean[r2], rstd[r2]);
+        }
+      }
+      const int k_last4 = ((K + 3) & ~3) - 4, ldxh = (K + 3) & ~3;
+      float dot[2] = {0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < nq) {
+          const int k = 4 * lane + 256 * q;
+          float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f), wo = bt;
+          if (p.has_ln) {
+            g = *reinterpret_cast<const float4*>(p.gamma[j] + min(k, k_last4));
+            bt = *reinterpret_cast<const float4*>(p.beta[j] + min(k, k_last4));
+          }
+          if (last) wo = *reinterpret_cast<const float4*>(Wj + min(k, k_last4));
+#pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2) {
+            const int row = 2 * w + r2;
+            const float rs = pad[r2] ? 0.f : rstd[r2], mu = pad[r2] ? 0.f : mean[r2];
+            float4 xh, a;  // (x - mean) * rstd * gamma + beta ; a zero feature row normalises to beta
+            xh.x = k < K ? (xv[r2][q].x - mu) * rs : 0.f;
+            xh.y = k + 1 < K ? (xv[r2][q].y - mu) * rs : 0.f;
+            xh.z = k + 2 < K ? (xv[r2][q].z - mu) * rs : 0.f;
+            xh.w = k + 3 < K ? (xv[r2][q].w - mu) * rs : 0.f;
+            a.x = k < K ? fmaf(xh.x, g.x, bt.x) : 0.f;
+            a.y = k + 1 < K ? fmaf(xh.y, g.y, bt.y) : 0.f;
+            a.z = k + 2 < K ? fmaf(xh.z, g.z, bt.z) : 0.f;
+            a.w = k + 3 < K ? fmaf(xh.w, g.w, bt.w) : 0.f;
+            if (last) {
+              dot[r2] = fmaf(a.w, wo.w, fmaf(a.z, wo.z, fmaf(a.y, wo.y, fmaf(a.x, wo.x, dot[r2]))));
+            } else if (k < K16) {
+              *reinterpret_cast<float4*>(cur + row * PS + k) = a;
+              if (p.xhat_out[j] && m0 + row < p.M && k < ldxh)
+                *reinterpret_cast<float4*>(p.xhat_out[j] + (m0 + row) * ldxh + k) = xh;
+            }
+          }
+        }
+      if (last) {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const float sc = wave_sum(dot[r2]) + p.bias[j][0];
+          const long long m = m0 + 2 * w + r2;
+          if (lane == 0 && m < p.M) p.scores[m] = sc;
+        }
+        ULTR_STAMP(5, 7);
+        break;
+      }
+    }
+    ULTR_STAMP(5, min(1 + 2 * j, 6));
+    lds_barrier();
+
+    // ---- GEMM: this wave's units
+    for (int u = u_first; u < U; u += 8) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u != u_first) {
+        colc = min(64 * u + 4 * nn, ldn - 4);
+        CH_LOAD(0, S0);
+        CH_LOAD(1, S1);
+      }
+      auto compute = [&](Frag& S, int i) {
+        const float4 a4 = *reinterpret_cast<const float4*>(cur + nn * PS + 16 * (c_begin + i) + 4 * kk);
+        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].w, acc[3], 0, 0, 0);
+        }
+      };
+#define CH_COMPUTE(S, i) compute(S, i)
+      ULTR_STREAM_GEMM(nch, CH_LOAD, CH_COMPUTE);
+#undef CH_COMPUTE
+
+      if (KS > 1) {  // uniform over the workgroup (U < 8: exactly one unit per wave)
+        lds_barrier();  // the panel has been multiplied out: the exchange buffer takes its place
+        if (ks > 0) {
+          float* dst = cur + ((ks - 1) * Up + u) * 1024 + lane * 4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(dst + 256 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        }
+        lds_barrier();
+        if (ks == 0) {
+          for (int sl = 1; sl < KS; ++sl) {
+            const float* srcp = cur + ((sl - 1) * Up + u) * 1024 + lane * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float4 v = *reinterpret_cast<const float4*>(srcp + 256 * t);
+              acc[t][0] += v.x; acc[t][1] += v.y; acc[t][2] += v.z; acc[t][3] += v.w;
+            }
+          }
+        }
+      }
+      if (ks == 0) {
+        // epilogue: lane holds rows 4 kk + r (r = 0..3), columns col0 .. col0 + 3
+        const int col0 = 64 * u + 4 * nn;
+        const int nlast4 = ((N + 3) & ~3) - 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias[j] + min(col0, nlast4));
+        const int n16 = (N + 15) & ~15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float4 z = make_float4(acc[0][r] + b4.x, acc[1][r] + b4.y, acc[2][r] + b4.z, acc[3][r] + b4.w);
+          float4 v = act4_rt(p.activation, z);
+          v.x = col0 < N ? v.x : 0.f;
+          v.y = col0 + 1 < N ? v.y : 0.f;
+          v.z = col0 + 2 < N ? v.z : 0.f;
+          v.w = col0 + 3 < N ? v.w : 0.f;
+          const int row = 4 * kk + r;
+          if (col0 < n16) *reinterpret_cast<float4*>(nxt + row * PS + col0) = v;
+          if (col0 < ldn && m0 + row < p.M) *reinterpret_cast<float4*>(p.act_out[j] + (m0 + row) * ldn + col0) = v;
+        }
+      }
+    }
+#undef CH_LOAD
+    if (u_first >= U && KS > 1) {  // idle waves of a non-power-of-two unit count still meet the barriers
+      lds_barrier();
+      lds_barrier();
+    }
+    ULTR_STAMP(5, min(2 + 2 * j, 6));
+    lds_barrier();
+    float* t_ = cur; cur = nxt; nxt = t_;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward of the output layer: parameter-gradient partials + dz of the last hidden layer
 // ---------------------------------------------------------------------------------------------
 struct BwdOutArgs {
@@ -1338,6 +1606,49 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
   float* ws = reinterpret_cast<float*>(workspace);
   const int has_ln = desc->norm == ULTR_NORM_LAYER;
   hipStream_t st = as_stream(stream);
+  static const bool chain_on = [] { const char* e = getenv("ULTR_FWD_CHAIN"); return !(e && e[0] == '0'); }();
+  size_t chain_smem = 0;
+  int chain_ps = 0, chain_buf = 0;
+  if (chain_on && L.H >= 1 && L.K[0] <= 1024) {  // hidden widths are <= ULTR_MAX_WIDTH = 1024 (check_desc)
+    int maxw = L.K[0];
+    for (int j = 0; j < L.H; ++j) maxw = L.N[j] > maxw ? L.N[j] : maxw;
+    chain_ps = ((maxw + 31) & ~31) + 4;
+    chain_buf = kChainRows * chain_ps > kChainExch ? kChainRows * chain_ps : kChainExch;
+    chain_smem = 2 * (size_t)chain_buf * sizeof(float);
+  }
+  if (chain_smem > 0 && chain_smem <= 160 * 1024) {  // else: the per-layer kernels below
+    ChainArgs c{};
+    c.table = table; c.ldx = ldx; c.docids = docids; c.n_rows = n_rows; c.row_stats = table_stats;
+    c.has_ln = has_ln; c.eps = desc->ln_eps; c.activation = desc->activation; c.H = L.H; c.M = M;
+    long long pw = 0;
+    for (int j = 0; j <= L.H; ++j) {
+      c.W[j] = params + desc->off_W[j]; c.bias[j] = params + desc->off_b[j];
+      c.gamma[j] = params + desc->off_gamma[j]; c.beta[j] = params + desc->off_beta[j];
+      c.K[j] = L.K[j]; c.N[j] = L.N[j]; c.ldn[j] = L.ldn[j];
+      c.stat_out[j] = ws + L.stat[j];
+      if (j < L.H) {
+        c.act_out[j] = ws + L.act[j]; c.xhat_out[j] = ws + L.xhat[j];
+        pw += (long long)L.K[j] * L.N[j];
+      }
+    }
+    c.scores = scores;
+    c.PS = chain_ps;
+    c.buf_floats = chain_buf;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess) {
+        set_error("ultr_dnn_forward: cannot raise the dynamic LDS limit");
+        return ULTR_EHIP;
+      }
+      attr_done = true;
+    }
+    {
+      ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("fwd_chain_kernel/P%lld", pw) : "fwd_chain_kernel", st);
+      hipLaunchKernelGGL(fwd_chain_kernel, dim3((unsigned)cdiv(M, kChainRows)), dim3(kChainThreads), chain_smem, st, c);
+    }
+    return check_launch("fwd_chain_kernel");
+  }
   for (int j = 0; j < L.H; ++j) {
     FwdArgs a{};
     if (j == 0) {
