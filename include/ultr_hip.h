@@ -215,6 +215,17 @@ long long ultr_metrics_workspace_floats(int B, int n_topn);
 int ultr_metrics(const float* scores, const float* labels, const int* docids, int n_rows,
                  const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
                  int n_topn, int metric_mask, float max_label, float* out, float* ws, void* stream);
+
+/* ultr_metrics with the launch deferred: same arguments and results, but for lists of at most 64 entries nothing
+ * is launched here -- the request is parked and the NEXT ultr_dnn_backward call of this host thread carries it as
+ * extra workgroups of its largest weight-gradient launch (the in-step metrics of dla.py:189-221 need only the
+ * scores and the list weights, which exist before the backward pass; riding along takes their latency out of the
+ * chain of dependent launches).  All pointers must stay valid until that call.  Longer lists are evaluated at once.
+ * ultr_metrics_flush launches a parked request on its own (no-op when there is none). */
+int ultr_metrics_deferred(const float* scores, const float* labels, const int* docids, int n_rows,
+                 const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
+                 int n_topn, int metric_mask, float max_label, float* out, float* ws, void* stream);
+int ultr_metrics_flush(void* stream);
 /* The permutation itself: perm [B][topn] int32 = sort_by_scores(scores) indices. */
 int ultr_sort_by_scores(const float* scores, const float* u, int B, int Lx, int topn, int* perm,
                         void* stream);

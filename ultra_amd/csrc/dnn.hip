@@ -18,7 +18,7 @@
 //    by the finalize kernel; dW = gamma*G + beta x S, dgamma = sum_n W*G, dbeta = sum_n W*S, so
 //    layer 0 needs no dgrad GEMM at all), dgrad dh = dz W^T, then a row pass applies the
 //    LayerNorm backward and the activation derivative (from the stored activation output).
-#include "common.hpp"
+#include "metrics_body.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -672,6 +672,11 @@ __global__ void __launch_bounds__(kThreads) fwd_out_kernel(OutArgs p) {
 //     of a layer starts before its input rows are normalised.
 // ---------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+#ifdef ULTR_STAMPS
+#define CH_DBG(bit) (p.dbg & (bit))
+#else
+#define CH_DBG(bit) false
+#endif
 constexpr int kChainThreads = 512, kChainRows = 16, kChainExch = 7 * 1024;
 
 struct ChainArgs {
@@ -684,6 +689,7 @@ struct ChainArgs {
   float* scores;
   int PS;          // LDS panel row stride in floats, == 4 (mod 32)
   int buf_floats;  // each of the two LDS buffers
+  int dbg;         // diagnostic builds (-DULTR_STAMPS): 1 no weight loads, 2 no MFMAs, 4 no global stores
 };
 
 __device__ __forceinline__ float4 act4_rt(int kind, float4 z) {
@@ -729,6 +735,7 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
 #define CH_LOAD(i, S)                                                                              \
   do {                                                                                             \
     const int k0_ = 16 * min(c_begin + (i), c_last) + 4 * kk;                                      \
+    if (CH_DBG(1)) { _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) S.b[s_] = make_float4(1.f, 2.f, 3.f, (float)k0_); } else \
     _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                               \
       S.b[s_] = *reinterpret_cast<const float4*>(Wj + (size_t)min(k0_ + s_, K - 1) * ldn + colc);  \
   } while (0)
@@ -738,8 +745,25 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
     }
 
     // ---- input stage: wave w owns rows 2w and 2w+1; lanes run along the row (float4 each)
+    if (j == 1) ULTR_STAMP(6, 0);
     {
       const int nq = (K16 + 255) >> 8;  // <= 4 (widths <= 1024)
+      const int k_last4 = ((K + 3) & ~3) - 4, ldxh = (K + 3) & ~3;
+      // gamma / beta (and the output layer's weights) are requested first: their latency runs under the statistics
+      float4 gm[4], btq[4], woq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        gm[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        btq[q] = woq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) {
+          const int kc = min(4 * lane + 256 * q, k_last4);
+          if (p.has_ln) {
+            gm[q] = *reinterpret_cast<const float4*>(p.gamma[j] + kc);
+            btq[q] = *reinterpret_cast<const float4*>(p.beta[j] + kc);
+          }
+          if (last) woq[q] = *reinterpret_cast<const float4*>(Wj + kc);
+        }
+      }
       float4 xv[2][4];
       float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
       bool pad[2] = {false, false};
@@ -764,7 +788,7 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
             if (q < nq) xv[r2][q] = *reinterpret_cast<const float4*>(cur + row * PS + min(4 * lane + 256 * q, K16 - 4));
         }
       }
-      if (j > 0 && p.has_ln) {  // two-pass statistics of the two rows, interleaved
+      if (j > 0 && p.has_ln && !CH_DBG(8)) {  // two-pass statistics of the two rows, interleaved
         float sm[2], m2[2];
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
@@ -798,18 +822,13 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
           if (lane == 0 && m < p.M) *reinterpret_cast<float2*>(p.stat_out[j] + 2 * m) = make_float2(mean[r2], rstd[r2]);
         }
       }
-      const int k_last4 = ((K + 3) & ~3) - 4, ldxh = (K + 3) & ~3;
+      if (j == 1) ULTR_STAMP(6, 1);
       float dot[2] = {0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (q < nq) {
           const int k = 4 * lane + 256 * q;
-          float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f), wo = bt;
-          if (p.has_ln) {
-            g = *reinterpret_cast<const float4*>(p.gamma[j] + min(k, k_last4));
-            bt = *reinterpret_cast<const float4*>(p.beta[j] + min(k, k_last4));
-          }
-          if (last) wo = *reinterpret_cast<const float4*>(Wj + min(k, k_last4));
+          const float4 g = gm[q], bt = btq[q], wo = woq[q];
 #pragma unroll
           for (int r2 = 0; r2 < 2; ++r2) {
             const int row = 2 * w + r2;
@@ -827,7 +846,7 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
               dot[r2] = fmaf(a.w, wo.w, fmaf(a.z, wo.z, fmaf(a.y, wo.y, fmaf(a.x, wo.x, dot[r2]))));
             } else if (k < K16) {
               *reinterpret_cast<float4*>(cur + row * PS + k) = a;
-              if (p.xhat_out[j] && m0 + row < p.M && k < ldxh)
+              if (p.xhat_out[j] && m0 + row < p.M && k < ldxh && !CH_DBG(4))
                 *reinterpret_cast<float4*>(p.xhat_out[j] + (m0 + row) * ldxh + k) = xh;
             }
           }
@@ -844,7 +863,9 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
       }
     }
     ULTR_STAMP(5, min(1 + 2 * j, 6));
+    if (j == 1) ULTR_STAMP(6, 2);
     lds_barrier();
+    if (j == 1) ULTR_STAMP(6, 3);
 
     // ---- GEMM: this wave's units
     for (int u = u_first; u < U; u += 8) {
@@ -856,9 +877,15 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
         CH_LOAD(0, S0);
         CH_LOAD(1, S1);
       }
+      // the bias of this lane's four columns rides along with the weight stream
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bias[j] + min(64 * u + 4 * nn, ((N + 3) & ~3) - 4));
       auto compute = [&](Frag& S, int i) {
         const float4 a4 = *reinterpret_cast<const float4*>(cur + nn * PS + 16 * (c_begin + i) + 4 * kk);
         const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (CH_DBG(2)) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[s][0] += a[s] * (S.b[s].x + S.b[s].y + S.b[s].z + S.b[s].w);
+        } else
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].x, acc[0], 0, 0, 0);
@@ -869,9 +896,10 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
       };
 #define CH_COMPUTE(S, i) compute(S, i)
       ULTR_STREAM_GEMM(nch, CH_LOAD, CH_COMPUTE);
+      if (j == 1) ULTR_STAMP(6, 4);
 #undef CH_COMPUTE
 
-      if (KS > 1) {  // uniform over the workgroup (U < 8: exactly one unit per wave)
+      if (KS > 1 && !CH_DBG(16)) {  // uniform over the workgroup (U < 8: exactly one unit per wave)
         lds_barrier();  // the panel has been multiplied out: the exchange buffer takes its place
         if (ks > 0) {
           float* dst = cur + ((ks - 1) * Up + u) * 1024 + lane * 4;
@@ -890,33 +918,34 @@ __global__ void __launch_bounds__(kChainThreads) fwd_chain_kernel(ChainArgs p) {
           }
         }
       }
+      if (j == 1) ULTR_STAMP(6, 5);
       if (ks == 0) {
         // epilogue: lane holds rows 4 kk + r (r = 0..3), columns col0 .. col0 + 3
         const int col0 = 64 * u + 4 * nn;
-        const int nlast4 = ((N + 3) & ~3) - 4;
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias[j] + min(col0, nlast4));
         const int n16 = (N + 15) & ~15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float4 z = make_float4(acc[0][r] + b4.x, acc[1][r] + b4.y, acc[2][r] + b4.z, acc[3][r] + b4.w);
-          float4 v = act4_rt(p.activation, z);
+          float4 v = CH_DBG(32) ? z : act4_rt(p.activation, z);
           v.x = col0 < N ? v.x : 0.f;
           v.y = col0 + 1 < N ? v.y : 0.f;
           v.z = col0 + 2 < N ? v.z : 0.f;
           v.w = col0 + 3 < N ? v.w : 0.f;
           const int row = 4 * kk + r;
           if (col0 < n16) *reinterpret_cast<float4*>(nxt + row * PS + col0) = v;
-          if (col0 < ldn && m0 + row < p.M) *reinterpret_cast<float4*>(p.act_out[j] + (m0 + row) * ldn + col0) = v;
+          if (col0 < ldn && m0 + row < p.M && !CH_DBG(4)) *reinterpret_cast<float4*>(p.act_out[j] + (m0 + row) * ldn + col0) = v;
         }
       }
     }
 #undef CH_LOAD
-    if (u_first >= U && KS > 1) {  // idle waves of a non-power-of-two unit count still meet the barriers
+    if (u_first >= U && KS > 1 && !CH_DBG(16)) {  // idle waves of a non-power-of-two unit count still meet the barriers
       lds_barrier();
       lds_barrier();
     }
     ULTR_STAMP(5, min(2 + 2 * j, 6));
+    if (j == 1) ULTR_STAMP(6, 6);
     lds_barrier();
+    if (j == 1) ULTR_STAMP(6, 7);
     float* t_ = cur; cur = nxt; nxt = t_;
   }
 }
@@ -1319,6 +1348,31 @@ __global__ void __launch_bounds__(kThreads, 2) bwd_pair_kernel(BwdPairArgs p) {
   }
 }
 
+// The in-step metrics ride along with a weight-gradient launch (ultr_metrics_deferred): they need only the scores
+// and the list weights, so their 12 us of sort-and-sum latency on 16 CUs runs under a GEMM that is busy anyway
+// instead of holding a place of its own in the chain of dependent launches.  The rider workgroups come FIRST
+// (dispatched first, they are the longer pole), padded to a multiple of 8 so that the GEMM's workgroup-id -> XCD
+// mapping is unchanged.
+struct WgradRiderArgs {
+  WgradArgs g;
+  int g_gx, g_gy, g_gz;
+  MetricsArgs m;
+  int m_blocks, m_pad;
+};
+__global__ void __launch_bounds__(kThreads) wgrad_rider_kernel(WgradRiderArgs p) {
+  int id = blockIdx.x;
+  if (id >= p.m_pad) {
+    id -= p.m_pad;
+    wgrad_body(p.g, id % p.g_gx, (id / p.g_gx) % p.g_gy, id / (p.g_gx * p.g_gy));
+    return;
+  }
+  if (id >= p.m_blocks) return;
+  __shared__ float s_vals[4 * kMaxOut];
+  metrics_short_lists(p.m, id, p.m_blocks, s_vals);
+  __syncthreads();
+  metrics_finish(p.m, id, p.m_blocks, s_vals, kMetThreads / 64);
+}
+
 // ---------------------------------------------------------------------------------------------
 // row pass: dz = LayerNorm-backward(dh) * act'(a), in place.  One wave per row.
 //   g = dh*gamma ; dx = rstd * (g - mean(g) - xhat*mean(g*xhat)) ; dz = dx * act'(a)
@@ -1634,6 +1688,9 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
     c.scores = scores;
     c.PS = chain_ps;
     c.buf_floats = chain_buf;
+#ifdef ULTR_STAMPS
+    { const char* e = getenv("ULTR_CHAIN_DBG"); c.dbg = e ? atoi(e) : 0; }
+#endif
     static bool attr_done = false;
     if (!attr_done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1735,11 +1792,31 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
     rc = check_launch("bwd_out_kernel");
     if (rc) return rc;
   }
-  // Per layer: wgrad_j, dgrad_j, then the row pass that turns dh into dz_{j-1}.  ULTR_BWD_PAIR=1 runs the two GEMMs
-  // side by side in one launch (bwd_pair_kernel); measured at M = 2560 the pair costs the SUM of its parts (33.7 us
-  // against 17.4 + 16.6), i.e. these kernels are bound by a shared resource -- the memory side feeding just-written
-  // data -- not by latency, so the separate launches stay the default.
-  static const bool pair = [] { const char* e = getenv("ULTR_BWD_PAIR"); return e && e[0] == '1'; }();
+  // Per layer: wgrad_j, dgrad_j, then the row pass that turns dh into dz_{j-1}.  The two GEMMs of a layer can run
+  // side by side in one launch (bwd_pair_kernel).  For the big layer the pair costs the SUM of its parts -- both
+  // are bound by the memory side feeding just-written data, not by latency -- so only small layers are paired.
+  // ULTR_BWD_PAIR=<mask> (bit j-1: layer j) overrides the rule below; measured at M = 2560: pairing layer 2
+  // (K256 N128) 13.9 us against 9.4 + 8.8, pairing layer 1 (K512 N256) 34.0 us against 14.9 + 17.5
+  static const int pair_env = [] { const char* e = getenv("ULTR_BWD_PAIR"); return e ? atoi(e) : -1; }();
+  int pair_mask = 0;
+  if (pair_env >= 0) pair_mask = pair_env;
+  else
+    for (int j = 1; j < H; ++j)  // small GEMMs only: they leave most of the chip idle on their own
+      if (2.0 * (double)M * L.K[j] * L.N[j] <= 0.25e9) pair_mask |= 1 << (j - 1);
+  // A parked metric request (ultr_metrics_deferred) rides with layer 0's weight-gradient launch.  Measured at the
+  // headline shape (wgrad alone -> with the rider): layer 0 (K136 N512) 12.4 -> 15.3 us, layer 2 (K256 N128) 9.3 -> 15.0,
+  // layer 1 (K512 N256) 14.7 -> 24.1 against 14.4 us for a metric launch of its own: the heavier the carrier's operand
+  // streams, the longer the rider's dependent loads queue behind them.
+  int carrier = -1;
+  if (g_pending_metrics.on) {
+    if (H >= 1) carrier = 0;
+    if (const char* e = getenv("ULTR_RIDE_CARRIER")) carrier = atoi(e) < H && !pair_mask ? atoi(e) : carrier;  // experiments
+    if (carrier < 0) {
+      g_pending_metrics.on = false;
+      rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, st);
+      if (rc) return rc;
+    }
+  }
   for (int j = H - 1; j >= 0; --j) {
     WgradArgs g{};
     g.xhat = ws + L.xhat[j]; g.ldx = round4(L.K[j]);
@@ -1747,7 +1824,21 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
     g.K = L.K[j]; g.M = M; g.rows_per_split = L.rows_per_split[j];
     g.gslab = ws + L.gslab[j]; g.sslab = ws + L.sslab[j];
     const dim3 ggrid((unsigned)L.nsplit[j], (unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64));
-    if (j == 0 || !pair) {
+    const bool pair = j > 0 && j != carrier && ((pair_mask >> (j - 1)) & 1);
+    if (j == carrier) {
+      WgradRiderArgs wr{};
+      wr.g = g; wr.g_gx = (int)ggrid.x; wr.g_gy = (int)ggrid.y; wr.g_gz = (int)ggrid.z;
+      wr.m = g_pending_metrics.a; wr.m_blocks = (int)g_pending_metrics.nblocks; wr.m_pad = (wr.m_blocks + 7) & ~7;
+      g_pending_metrics.on = false;
+      const long long nblk = (long long)ggrid.x * ggrid.y * ggrid.z + wr.m_pad;
+      ULTR_REQUIRE(nblk < 2147483647ll, ULTR_ELIMIT, "ultr_dnn_backward: grid too large");
+      {
+        ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_rider_kernel/K%dN%d", L.K[j], L.N[j]) : "wgrad_rider_kernel", st);
+        hipLaunchKernelGGL(wgrad_rider_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, st, wr);
+      }
+      rc = check_launch("wgrad_rider_kernel");
+      if (rc) return rc;
+    } else if (j == 0 || !pair) {
       {
         ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_kernel/K%dN%d", L.K[j], L.N[j]) : "wgrad_kernel", st);
         hipLaunchKernelGGL(wgrad_kernel, ggrid, dim3(kThreads), 0, st, g);

@@ -242,12 +242,17 @@ class BaseAlgorithm(ABC):
     def _all_reduce(self, tb):
         parallel.all_reduce_bucket(tb['bucket'], tb['n_reduce'], self.world)
 
-    def _train_metrics(self, tb, batch, scores, weighted):
+    # ULTR_METRICS_RIDE=0: the metric kernel gets a launch of its own instead of riding with the backward pass
+    ride_metrics = os.environ.get('ULTR_METRICS_RIDE', '1') != '0'
+
+    def _train_metrics(self, tb, batch, scores, weighted, deferred=False):
         u = getattr(self, 'metric_uniforms', None)  # [B, L] tie-break uniforms supplied by the caller (tests)
         if u is None and self.shuffle_ties:
             u = torch.rand((batch.B, scores.shape[0]), dtype=torch.float32, device=self.device)
+        tb['metric_u'] = u  # kept alive until the backward pass has carried a deferred request
         dev_metrics.batch_metrics(self.train_plan, scores, batch.labels, batch.docids, batch.n_rows,
-                                  tb['list_weights'] if weighted else None, tb['metrics'], tb['met_ws'], u)
+                                  tb['list_weights'] if weighted else None, tb['metrics'], tb['met_ws'], u,
+                                  deferred=deferred)
 
     def _publish(self, tb):
         """Async copy of [stats | metrics | local] to a pinned ring slot; returns fetch() -> numpy row."""
@@ -300,8 +305,11 @@ class BaseAlgorithm(ABC):
             self.model.backward(tb['d_scores'], tb['grads'])   # flat un-normalised gradient
             main.wait_stream(side)
         else:
-            self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS)
+            # the request is parked and carried by the backward pass inside one of its own launches
+            self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS, deferred=self.ride_metrics)
             self.model.backward(tb['d_scores'], tb['grads'])
+            if self.ride_metrics:
+                _lib.check(_lib.lib().ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
         self._pending = (tb, batch)
 
     def step_reduce(self):

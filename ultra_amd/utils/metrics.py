@@ -65,11 +65,16 @@ def metrics_workspace(B, plan, device):
     return torch.zeros(n, dtype=torch.float32, device=device)
 
 
-def batch_metrics(plan, scores_lb, labels_lb, docids_lb, n_rows, list_weights, out, ws, u_pred=None, max_label=None):
-    """scores/labels/docids position-major [L][B] device tensors -> out[plan.n_out] (device, in place)."""
+def batch_metrics(plan, scores_lb, labels_lb, docids_lb, n_rows, list_weights, out, ws, u_pred=None, max_label=None,
+                  deferred=False):
+    """scores/labels/docids position-major [L][B] device tensors -> out[plan.n_out] (device, in place).
+
+    deferred=True parks the request: the next ``ultr_dnn_backward`` of this thread carries it inside one of its own
+    launches (``ultr_metrics_deferred``); every tensor passed here must stay alive until then."""
     L, B = scores_lb.shape
     ml = max_label if max_label is not None else (RankingMetricKey.MAX_LABEL or 0.0)
-    _lib.check(_lib.lib().ultr_metrics(
+    fn = _lib.lib().ultr_metrics_deferred if deferred else _lib.lib().ultr_metrics
+    _lib.check(fn(
         _lib.ptr(scores_lb), _lib.ptr(labels_lb), _lib.ptr(docids_lb), int(n_rows), _lib.ptr(list_weights),
         _lib.ptr(u_pred), int(B), int(L), plan.topn_c, len(plan.topn), plan.mask, float(ml), _lib.ptr(out),
         _lib.ptr(ws), _lib.current_stream()), 'ultr_metrics')
