@@ -5,6 +5,7 @@ losses / gradients / propensities within 1e-5 relative in fp32 (tensor-wise L2-r
 oracle is float64, the kernels are exact fp32 -- fmaf-chain MFMA -- so the bound is fp32 rounding).
 """
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -527,3 +528,22 @@ def test_dnn_build_reference_api(L):
     assert np.abs(b0).max() > 0 and np.abs(b0).max() <= np.sqrt(6.0 / 64) + 1e-6
     with pytest.raises(NotImplementedError):
         DNN('norm=batch').create_variables(8, 'cuda')
+
+
+@pytest.mark.parametrize('env', [{'ULTR_FWD_CHAIN': '0'}, {'ULTR_BWD_CHAIN': '1'}, {'ULTR_BWD_PAIR': '3'},
+                                 {'ULTR_METRICS_RIDE': '0'}])
+def test_alternate_kernel_paths_in_a_fresh_process(env):
+    """The library picks its launch plan from the shapes; the plans that the default shapes no longer reach (per-layer
+    forward kernels, the backward chain, paired wgrad+dgrad for every layer, a metric launch of its own) are switched
+    on through their environment variables -- read once per process, hence the subprocess -- and must pass the same
+    DNN forward/backward and training-step parity tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
+                        'tests/test_gpu_kernels.py', 'tests/test_gpu_step.py', '-k',
+                        'dnn_forward_backward or dla_steps_match or naive_steps_match'],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

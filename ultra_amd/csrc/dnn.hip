@@ -1431,6 +1431,242 @@ __global__ void __launch_bounds__(kThreads) rowpass_kernel(RowpassArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward chain: the dgrad GEMMs and the row passes of ALL hidden layers for 16 rows in one workgroup.
+//
+// dz_{j-1} = rowpass_j( dz_j . W_j^T ) is a per-row recurrence just like the forward pass, so for small batches the
+// chain  dgrad_{H-1} -> row pass -> dgrad_{H-2} -> row pass -> ... -> dz_0  runs out of LDS in one launch
+// (same workgroup shape, MFMA tiling and weight streaming as fwd_chain_kernel).  It starts from the dz_{H-1} that
+// bwd_out_kernel wrote and leaves every dz_j in its own buffer for the weight-gradient GEMMs that follow.
+//   B operand: W_j is row-major [K_j][ldn] and the contraction runs along its rows, so a lane's float4 holds four
+//   contraction STEPS of one output column (forward: four columns of one step); the lane's four accumulators still
+//   end up as 4 rows x 4 consecutive columns.
+// ---------------------------------------------------------------------------------------------
+struct BwdChainArgs {
+  int has_ln, activation, H;
+  long long M;
+  const float* W[ULTR_MAX_LAYERS];      // W_j   [K_j][ldn_j]
+  const float* gamma[ULTR_MAX_LAYERS];  // gamma of layer j's input LayerNorm [K_j]
+  const float* act[ULTR_MAX_LAYERS];    // activations of hidden layer j [M][ldn_j]
+  const float* stat[ULTR_MAX_LAYERS];   // (mean, rstd) of layer j's input rows [M][2], j >= 1
+  float* dz[ULTR_MAX_LAYERS];           // dz_j [M][ldn_j]: dz_{H-1} is read, the others are written
+  int K[ULTR_MAX_LAYERS], N[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS];
+  int PS, buf_floats;
+};
+
+__global__ void __launch_bounds__(kChainThreads) bwd_chain_kernel(BwdChainArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nn = lane & 15, kk = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * kChainRows;
+  const int PS = p.PS;
+  float* cur = smem;
+  float* nxt = smem + p.buf_floats;
+  struct Frag { float4 b[4]; } S0, S1, S2;
+  ULTR_STAMP(7, 0);
+
+  {  // dz of the last hidden layer (written by bwd_out_kernel) -> LDS, zero beyond its width
+    const int j = p.H - 1, N = p.N[j], ld = p.ldn[j], N16 = (N + 15) & ~15;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int row = 2 * w + r2;
+      const long long m = min(m0 + row, p.M - 1);
+      for (int k = 4 * lane; k < N16; k += 256) {
+        float4 v = *reinterpret_cast<const float4*>(p.dz[j] + m * ld + min(k, ld - 4));
+        v.x = k < N ? v.x : 0.f;
+        v.y = k + 1 < N ? v.y : 0.f;
+        v.z = k + 2 < N ? v.z : 0.f;
+        v.w = k + 3 < N ? v.w : 0.f;
+        *reinterpret_cast<float4*>(cur + row * PS + k) = v;
+      }
+    }
+  }
+
+  for (int j = p.H - 1; j >= 1; --j) {
+    // dy[16][K] = dz_j[16][Nc] . W_j^T : output columns c < K (= width of layer j-1), contraction n < Nc
+    const int K = p.K[j], Nc = p.N[j], ldw = p.ldn[j], ldo = p.ldn[j - 1];
+    const int K16 = (K + 15) & ~15;
+    const int U = (K + 63) >> 6;
+    int Up = 1;
+    while (Up < U && Up < 8) Up <<= 1;
+    const int KS = U >= 8 ? 1 : 8 / Up;
+    const int ks = U >= 8 ? 0 : w / Up;
+    const int u_first = U >= 8 ? w : w % Up;
+    const int nchunks = (Nc + 15) >> 4, cps = (nchunks + KS - 1) / KS;
+    const int c_begin = ks * cps, c_end = min(c_begin + cps, nchunks);
+    const int nch = max(c_end - c_begin, 0), c_last = max(c_end - 1, 0);
+    const float* __restrict__ Wj = p.W[j];
+    int crow = 64 * u_first + 4 * nn;  // first of this lane's four output columns = four rows of W_j
+#define BC_LOAD(i, S)                                                                                  \
+  do {                                                                                                 \
+    const int n0_ = min(16 * min(c_begin + (i), c_last) + 4 * kk, ldw - 4);                            \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                                   \
+      S.b[t_] = *reinterpret_cast<const float4*>(Wj + (size_t)min(crow + t_, K - 1) * ldw + n0_);      \
+  } while (0)
+    if (u_first < U) {
+      BC_LOAD(0, S0);
+      BC_LOAD(1, S1);
+    }
+    // what the row pass will need, requested now: the activations of layer j-1 (two rows per wave), gamma, statistics
+    const int nq = (K16 + 255) >> 8;  // <= 4
+    const int k_last4 = ((K + 3) & ~3) - 4;
+    float4 hv[2][4], gm[4];
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      gm[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (q < nq) {
+        const int kc = min(4 * lane + 256 * q, k_last4);
+        if (p.has_ln) gm[q] = *reinterpret_cast<const float4*>(p.gamma[j] + kc);
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const long long m = min(m0 + 2 * w + r2, p.M - 1);
+          hv[r2][q] = *reinterpret_cast<const float4*>(p.act[j - 1] + m * ldo + min(4 * lane + 256 * q, ldo - 4));
+        }
+      }
+    }
+    if (p.has_ln) {
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const long long m = min(m0 + 2 * w + r2, p.M - 1);
+        const float2 st = *reinterpret_cast<const float2*>(p.stat[j] + 2 * m);
+        mean[r2] = st.x;
+        rstd[r2] = st.y;
+      }
+    }
+    lds_barrier();  // the panel (first layer: the staged dz, later: the row pass output) is complete
+    ULTR_STAMP(7, min(1 + 2 * (p.H - 1 - j), 6));
+
+    for (int u = u_first; u < U; u += 8) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u != u_first) {
+        crow = 64 * u + 4 * nn;
+        BC_LOAD(0, S0);
+        BC_LOAD(1, S1);
+      }
+      auto compute = [&](Frag& S, int i) {
+        const float4 a4 = *reinterpret_cast<const float4*>(cur + nn * PS + 16 * (c_begin + i) + 4 * kk);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, S.b[0].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, S.b[1].x, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, S.b[2].x, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, S.b[3].x, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, S.b[0].y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, S.b[1].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, S.b[2].y, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, S.b[3].y, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, S.b[0].z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, S.b[1].z, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, S.b[2].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, S.b[3].z, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, S.b[0].w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, S.b[1].w, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, S.b[2].w, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, S.b[3].w, acc[3], 0, 0, 0);
+      };
+#define BC_COMPUTE(S, i) compute(S, i)
+      ULTR_STREAM_GEMM(nch, BC_LOAD, BC_COMPUTE);
+#undef BC_COMPUTE
+
+      if (KS > 1) {  // uniform over the workgroup (U < 8: exactly one unit per wave)
+        lds_barrier();  // the panel has been multiplied out: the exchange buffer takes its place
+        if (ks > 0) {
+          float* dst = cur + ((ks - 1) * Up + u) * 1024 + lane * 4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(dst + 256 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        }
+        lds_barrier();
+        if (ks == 0) {
+          for (int sl = 1; sl < KS; ++sl) {
+            const float* srcp = cur + ((sl - 1) * Up + u) * 1024 + lane * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float4 v = *reinterpret_cast<const float4*>(srcp + 256 * t);
+              acc[t][0] += v.x; acc[t][1] += v.y; acc[t][2] += v.z; acc[t][3] += v.w;
+            }
+          }
+        }
+      }
+      if (ks == 0) {  // lane holds rows 4 kk + r (r = 0..3), columns col0 .. col0 + 3 of dy
+        const int col0 = 64 * u + 4 * nn;
+        if (col0 < K16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(nxt + (4 * kk + r) * PS + col0) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
+      }
+    }
+#undef BC_LOAD
+    if (u_first >= U && KS > 1) {  // idle waves of a non-power-of-two unit count still meet the barriers
+      lds_barrier();
+      lds_barrier();
+    }
+    ULTR_STAMP(7, min(2 + 2 * (p.H - 1 - j), 6));
+    lds_barrier();
+
+    // ---- row pass on rows 2w, 2w+1 of dy:  g = dy*gamma ; dx = rstd (g - mean(g) - xhat mean(g xhat)) ; dz = dx act'(h)
+    {
+      float4 dv[2][4];
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nq) dv[r2][q] = *reinterpret_cast<const float4*>(nxt + (2 * w + r2) * PS + min(4 * lane + 256 * q, K16 - 4));
+      float c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
+      if (p.has_ln) {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              const float dd[4] = {dv[r2][q].x, dv[r2][q].y, dv[r2][q].z, dv[r2][q].w};
+              const float gg[4] = {gm[q].x, gm[q].y, gm[q].z, gm[q].w};
+              const float hh[4] = {hv[r2][q].x, hv[r2][q].y, hv[r2][q].z, hv[r2][q].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float g = k + e < K ? dd[e] * gg[e] : 0.f;
+                c1[r2] += g;
+                c2[r2] += g * (hh[e] - mean[r2]) * rstd[r2];
+              }
+            }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          c1[r2] = wave_sum(c1[r2]) / (float)K;
+          c2[r2] = wave_sum(c2[r2]) / (float)K;
+        }
+      }
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int row = 2 * w + r2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nq) {
+            const int k = 4 * lane + 256 * q;
+            const float dd[4] = {dv[r2][q].x, dv[r2][q].y, dv[r2][q].z, dv[r2][q].w};
+            const float gg[4] = {gm[q].x, gm[q].y, gm[q].z, gm[q].w};
+            const float hh[4] = {hv[r2][q].x, hv[r2][q].y, hv[r2][q].z, hv[r2][q].w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float dx = dd[e];
+              if (p.has_ln) dx = rstd[r2] * (dx * gg[e] - c1[r2] - (hh[e] - mean[r2]) * rstd[r2] * c2[r2]);
+              o[e] = k + e < K ? dx * act_grad_from_out(p.activation, hh[e]) : 0.f;
+            }
+            const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+            if (k < K16) *reinterpret_cast<float4*>(nxt + row * PS + k) = ov;
+            if (k < ldo && m0 + row < p.M) *reinterpret_cast<float4*>(p.dz[j - 1] + (m0 + row) * ldo + k) = ov;
+          }
+      }
+    }
+    float* t_ = cur; cur = nxt; nxt = t_;
+    // the barrier at the top of the next layer (or the end of the kernel) orders these LDS writes
+  }
+  ULTR_STAMP(7, 7);
+}
+
+// ---------------------------------------------------------------------------------------------
 // finalize: reduce slabs in fixed order and form the parameter gradients
 //   dW[k][n] = gamma_k G[k][n] + beta_k S[n] ; db[n] = S[n]
 //   dgamma_k = sum_n W[k][n] G[k][n] ; dbeta_k = sum_n W[k][n] S[n]
@@ -1807,6 +2043,46 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
   // headline shape (wgrad alone -> with the rider): layer 0 (K136 N512) 12.4 -> 15.3 us, layer 2 (K256 N128) 9.3 -> 15.0,
   // layer 1 (K512 N256) 14.7 -> 24.1 against 14.4 us for a metric launch of its own: the heavier the carrier's operand
   // streams, the longer the rider's dependent loads queue behind them.
+  // ULTR_BWD_CHAIN=1: every dgrad GEMM and row pass in ONE launch (bwd_chain_kernel), the weight gradients follow.
+  // Opt-in: measured at M = 2560 the chain takes 37.9 us against 45 us for the launches it replaces, but the step
+  // as a whole replays 8 us SLOWER (156 against 148 us) -- 160 workgroups of 16 rows stream every weight through
+  // every CU and leave 96 CUs idle, and wgrad_2 loses its place beside dgrad_2.
+  static const bool bchain_env = [] { const char* e = getenv("ULTR_BWD_CHAIN"); return e && e[0] == '1'; }();
+  bool use_chain = bchain_env && H >= 2 && H <= 3;
+  if (use_chain) {
+    BwdChainArgs c{};
+    c.has_ln = has_ln; c.activation = desc->activation; c.H = H; c.M = M;
+    int maxw = L.N[H - 1];
+    for (int j = 0; j < H; ++j) {
+      c.W[j] = params + desc->off_W[j]; c.gamma[j] = params + desc->off_gamma[j];
+      c.act[j] = ws + L.act[j]; c.stat[j] = ws + L.stat[j];
+      c.dz[j] = ws + L.dz[(H - 1 - j) % 3];
+      c.K[j] = L.K[j]; c.N[j] = L.N[j]; c.ldn[j] = L.ldn[j];
+      if (j >= 1 && L.K[j] > maxw) maxw = L.K[j];
+    }
+    c.PS = ((maxw + 31) & ~31) + 4;
+    c.buf_floats = kChainRows * c.PS > kChainExch ? kChainRows * c.PS : kChainExch;
+    const size_t smem = 2 * (size_t)c.buf_floats * sizeof(float);
+    if (smem > 160 * 1024) {
+      use_chain = false;
+    } else {
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) {
+          set_error("ultr_dnn_backward: cannot raise the dynamic LDS limit");
+          return ULTR_EHIP;
+        }
+        attr_done = true;
+      }
+      {
+        ultr::ProfScope prof_("bwd_chain_kernel", st);
+        hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)cdiv(M, kChainRows)), dim3(kChainThreads), smem, st, c);
+      }
+      rc = check_launch("bwd_chain_kernel");
+      if (rc) return rc;
+    }
+  }
   int carrier = -1;
   if (g_pending_metrics.on) {
     if (H >= 1) carrier = 0;
@@ -1824,7 +2100,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
     g.K = L.K[j]; g.M = M; g.rows_per_split = L.rows_per_split[j];
     g.gslab = ws + L.gslab[j]; g.sslab = ws + L.sslab[j];
     const dim3 ggrid((unsigned)L.nsplit[j], (unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64));
-    const bool pair = j > 0 && j != carrier && ((pair_mask >> (j - 1)) & 1);
+    const bool pair = !use_chain && j > 0 && j != carrier && ((pair_mask >> (j - 1)) & 1);
     if (j == carrier) {
       WgradRiderArgs wr{};
       wr.g = g; wr.g_gx = (int)ggrid.x; wr.g_gy = (int)ggrid.y; wr.g_gz = (int)ggrid.z;
@@ -1846,7 +2122,9 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
       rc = check_launch("wgrad_kernel");
       if (rc) return rc;
     }
-    if (j > 0) {
+    if (j > 0 && use_chain) {
+      cur = (cur + 1) % 3;  // dz_{j-1} is where the chain kernel left it
+    } else if (j > 0) {
       const int nxt = (cur + 1) % 3;
       DgradArgs d{};
       d.dz = ws + L.dz[cur]; d.ldn = L.ldn[j]; d.N = L.N[j];
