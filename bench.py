@@ -54,11 +54,15 @@ def train_flops_per_list(F, L):
 
 
 def kernel_flops_per_launch(name, M):
-    """GEMM launches are reported as '<kernel>/K<k>N<n>' (csrc/dnn.hip): 2 M k n flops each."""
+    """GEMM launches are reported as '<kernel>/K<k>N<n>' (csrc/dnn.hip): 2 M k n flops each; the forward chain
+    (all hidden layers in one launch) as '<kernel>/P<sum of k n>': 2 M P."""
     m = re.search(r'/K(\d+)N(\d+)$', name)
-    if not m:
-        return None
-    return 2.0 * M * int(m.group(1)) * int(m.group(2))
+    if m:
+        return 2.0 * M * int(m.group(1)) * int(m.group(2))
+    m = re.search(r'/P(\d+)$', name)
+    if m:
+        return 2.0 * M * int(m.group(1))
+    return None
 
 
 def measured_traffic(kernel):
@@ -307,7 +311,7 @@ def main():
             name, fl, ms = best
             achieved = fl / (ms * 1e-3) / 1e12
             kname = name.split('/')[0]
-            roofline = {'kernel': kname, 'gemm': name.split('/')[1], 'bound': 'mfma', 'achieved': round(achieved, 3),
+            roofline = {'kernel': kname, 'gemm': name.split('/')[1] + (' (sum of K N over the hidden layers)' if '/P' in name else ''), 'bound': 'mfma', 'achieved': round(achieved, 3),
                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': measured_traffic(kname),
                         'launch_us': round(1e3 * ms, 3), 'flops_per_launch': fl}
