@@ -66,6 +66,30 @@ def main():
     json.dump(res, open(os.path.join(dst, tag + '_traffic.json'), 'w'), indent=1, sort_keys=True)
     for k, v in res['kernels'].items():
         print('%-60s fetch %10d  write %10d' % (k[:60], v['fetch_bytes'], v['write_bytes']))
+    sq = glob.glob(os.path.join(src, 'sq', '*', '*_counter_collection.csv'))
+    if sq:
+        path = max(sq, key=os.path.getmtime)
+        names = ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY',
+                 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU_MFMA_MOPS_F32', 'SQ_LDS_BANK_CONFLICT', 'GRBM_GUI_ACTIVE']
+        per = {n: per_kernel_mean(path, n) for n in names}
+        lines = ['# per launch, mean over the launches of the pass (rocprofv3 --pmc, tools/collect_profiles.sh pass 4)',
+                 '# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs); GRBM_GUI_ACTIVE is',
+                 '# summed over the 8 XCDs (MI355X_MICROARCH.md) and reads high on launches this short, so the figure is a',
+                 '# lower bound; wait/active are shares of SQ_WAVE_CYCLES (quad-cycles)',
+                 '%-44s %12s %12s %9s %8s %8s %8s %12s %10s' % ('kernel', 'mfma_busy', 'gui_active', 'mfma_util', 'wait', 'stall',
+                                                               'active', 'mfma_mops', 'lds_confl')]
+        for k in sorted(per['SQ_WAVE_CYCLES']):
+            if 'ultr' not in k and '_kernel' not in k:
+                continue
+            g = lambda n: per[n].get(k, 0.0)
+            wc = max(g('SQ_WAVE_CYCLES'), 1.0)
+            util = g('SQ_VALU_MFMA_BUSY_CYCLES') / max(g('GRBM_GUI_ACTIVE') / 8.0 * 256 * 4, 1.0)
+            lines.append('%-44s %12.0f %12.0f %8.1f%% %7.1f%% %7.1f%% %7.1f%% %12.0f %10.0f' % (
+                k[:44], g('SQ_VALU_MFMA_BUSY_CYCLES'), g('GRBM_GUI_ACTIVE'), 100 * util, 100 * g('SQ_WAIT_ANY') / wc,
+                100 * g('SQ_WAIT_INST_ANY') / wc, 100 * g('SQ_ACTIVE_INST_ANY') / wc, g('SQ_INSTS_VALU_MFMA_MOPS_F32'),
+                g('SQ_LDS_BANK_CONFLICT')))
+        open(os.path.join(dst, tag + '_mfma_util.txt'), 'w').write('\n'.join(lines) + '\n')
+        print('\n'.join(lines))
 
 
 if __name__ == '__main__':
