@@ -140,6 +140,15 @@ int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, const float*
                       const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
                       void* workspace, const float* d_scores, float* grads, void* stream);
 
+/* ultr_dnn_backward that also leaves the sum of squares of the gradient it wrote, as ultr_dnn_sumsq_count(desc)
+ * partial sums (one per workgroup of its last launch; their total is ||grads[0..n_params)||^2).  ultr_clip_adagrad3
+ * takes them in place of a norm pass over the gradient (tf.clip_by_global_norm, dla.py:240-245) -- valid as long as
+ * the gradient is not changed in between, i.e. on a single GPU. */
+int ultr_dnn_sumsq_count(const UltrDnnDesc* desc);
+int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const float* table,
+                            const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                            void* workspace, const float* d_scores, float* grads, float* sumsq, void* stream);
+
 /* ---- losses, forward + backward in one pass -------------------------------------------
  * All take scores/clicks position-major [L][B] and write d_scores [L][B] UN-NORMALISED: the
  * caller's optimiser call divides by the batch-global normaliser in `stats` (this is what
@@ -249,6 +258,25 @@ int ultr_clip_adagrad2(float* theta, float* acc, const float* grads, long long n
                        float* ws, float* theta_s, float* acc_s, const float* grads_s, int n_s,
                        const float* denom_s, float scale_const_s, float l2_s, float clip_norm_s, float lr_s,
                        float* out_norm_s, void* stream);
+
+/* The fused tail of a training step: ultr_clip_adagrad2 (small group optional: theta_s may be NULL) plus two
+ * options, each of which removes one launch from the chain of dependent kernels.
+ *   sumsq != NULL (and l2 == 0): the norm is formed from n_sumsq partial sums of squares of grads[0..n_covered)
+ *     (ultr_dnn_backward_sumsq) plus the squares of grads[n_covered..n), n - n_covered <= 65536, instead of a
+ *     pass over the gradient; the small group then rides with the update launch.
+ *   publish_n > 0: workgroup 0 copies publish_n floats publish_src -> publish_dst, with out_norm / out_norm_s
+ *     taken fresh when they lie inside the source range.  publish_dst may be device memory or the device-side
+ *     address of pinned host memory (ultr_host_device_pointer): the step's results row reaches the host without
+ *     a copy of its own (the reference returns loss and summary from session.run, dla.py:308-341). */
+int ultr_clip_adagrad3(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                       float scale_const, float l2, float clip_norm, float lr, int strategy, float* out_norm,
+                       float* ws, float* theta_s, float* acc_s, const float* grads_s, int n_s,
+                       const float* denom_s, float scale_const_s, float l2_s, float clip_norm_s, float lr_s,
+                       float* out_norm_s, const float* sumsq, int n_sumsq, long long n_covered,
+                       const float* publish_src, float* publish_dst, int publish_n, void* stream);
+
+/* Device-side address of a pinned (page-locked, mapped) host allocation; ULTR_EINVAL if the memory is not mapped. */
+int ultr_host_device_pointer(void* host, void** device);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,8 @@ SIGNATURES = {
     'ultr_dnn_workspace_bytes': (_LL, [_DESC, _LL]),
     'ultr_dnn_forward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P]),
     'ultr_dnn_backward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P, _P]),
+    'ultr_dnn_backward_sumsq': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P, _P, _P]),
+    'ultr_dnn_sumsq_count': (_I, [_DESC]),
     'ultr_loss_workspace_floats': (_LL, [_I, _I]),
     'ultr_loss_ipw_fwdbwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'ultr_ipw_weights': (_I, [_P, _I, _I, _P, _I, _P, _P]),
@@ -77,9 +79,12 @@ SIGNATURES = {
     'ultr_metrics': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
     'ultr_metrics_deferred': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
     'ultr_metrics_flush': (_I, [_P]),
+    'ultr_host_device_pointer': (_I, [_P, ctypes.POINTER(ctypes.c_void_p)]),
     'ultr_sort_by_scores': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ultr_clip_adagrad': (_I, [_P, _P, _P, _LL, _P, _F, _F, _F, _F, _I, _P, _P, _P]),
     'ultr_clip_adagrad2': (_I, [_P, _P, _P, _LL, _P, _F, _F, _F, _F, _I, _P, _P, _P, _P, _P, _I, _P, _F, _F, _F, _F, _P, _P]),
+    'ultr_clip_adagrad3': (_I, [_P, _P, _P, _LL, _P, _F, _F, _F, _F, _I, _P, _P, _P, _P, _P, _I, _P, _F, _F, _F, _F, _P,
+                                _P, _I, _LL, _P, _P, _I, _P]),
 }
 
 _lib = None
@@ -114,6 +119,14 @@ def ptr(t):
 
 
 _raw_stream = None
+
+
+def host_device_ptr(t):
+    """Device-side address of a pinned host tensor (None if the memory is not mapped for the GPU)."""
+    out = ctypes.c_void_p()
+    if lib().ultr_host_device_pointer(ctypes.c_void_p(t.data_ptr()), ctypes.byref(out)) != 0 or not out.value:
+        return None
+    return out
 
 
 def current_stream():

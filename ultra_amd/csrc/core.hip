@@ -105,5 +105,17 @@ extern "C" int ultr_profile_report(char* buf, int buflen) {
   return n;
 }
 
+extern "C" int ultr_host_device_pointer(void* host, void** device) {
+  ULTR_REQUIRE(host && device, ULTR_EINVAL, "ultr_host_device_pointer: null pointer");
+  *device = nullptr;
+  if (hipHostGetDevicePointer(device, host, 0) != hipSuccess || !*device) {
+    (void)hipGetLastError();
+    ultr::set_error("ultr_host_device_pointer: %p is not mapped pinned host memory", host);
+    *device = nullptr;
+    return ULTR_EINVAL;
+  }
+  return ULTR_OK;
+}
+
 extern "C" int ultr_version(void) { return ULTR_VERSION; }
 extern "C" const char* ultr_last_error(void) { return ultr::g_err; }

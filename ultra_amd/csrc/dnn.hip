@@ -1683,6 +1683,7 @@ struct FinalizeArgs {
   float* grads;
   int has_ln;
   const float* outpart; int out_blocks; int Kout;
+  float* sumsq;  // != NULL: [gridDim.x] sum of squares of what each workgroup stored into grads (norm partials)
 };
 
 __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
@@ -1704,12 +1705,19 @@ __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
     }
     s_col[g][c] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     __syncthreads();
+    float q[1] = {0.f};
     if (g == 0 && i < 3 * K + 1) {
       const float sum = (s_col[0][c] + s_col[1][c]) + (s_col[2][c] + s_col[3][c]);
+      bool stored = true;
       if (i < K) p.grads[p.off_W[j] + i] = sum;  // W_out is a plain [K] vector
-      else if (i < 2 * K) { if (p.has_ln) p.grads[p.off_gamma[j] + (i - K)] = sum; }
-      else if (i < 3 * K) { if (p.has_ln) p.grads[p.off_beta[j] + (i - 2 * K)] = sum; }
+      else if (i < 2 * K) { if (p.has_ln) p.grads[p.off_gamma[j] + (i - K)] = sum; else stored = false; }
+      else if (i < 3 * K) { if (p.has_ln) p.grads[p.off_beta[j] + (i - 2 * K)] = sum; else stored = false; }
       else p.grads[p.off_b[j]] = sum;
+      q[0] = stored ? sum * sum : 0.f;
+    }
+    if (p.sumsq) {
+      block_sum<1>(q, red);
+      if (threadIdx.x == 0) p.sumsq[blk] = q[0];
     }
     return;
   }
@@ -1721,7 +1729,7 @@ __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
   float* dW = p.grads + p.off_W[j] + (long long)k * ldn;
   const float gam = p.has_ln ? p.params[p.off_gamma[j] + k] : 1.f;
   const float bet = p.has_ln ? p.params[p.off_beta[j] + k] : 0.f;
-  float v[2] = {0.f, 0.f};
+  float v[2] = {0.f, 0.f}, q[1] = {0.f};
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     // slabs are summed in a fixed order; 4 independent partial sums keep 8 loads in flight
     float G4[4] = {0.f, 0.f, 0.f, 0.f}, S4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1741,11 +1749,16 @@ __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
       S4[0] += sp[(long long)s * ldn];
     }
     const float G = (G4[0] + G4[1]) + (G4[2] + G4[3]), S = (S4[0] + S4[1]) + (S4[2] + S4[3]);
-    dW[n] = gam * G + bet * S;
+    const float dw = gam * G + bet * S;
+    dW[n] = dw;
+    q[0] += dw * dw;
     const float wv = W[n];
     v[0] += wv * G;
     v[1] += wv * S;
-    if (k == 0) p.grads[p.off_b[j] + n] = S;
+    if (k == 0) {
+      p.grads[p.off_b[j] + n] = S;
+      q[0] += S * S;
+    }
   }
   if (p.has_ln) {
     block_sum<2>(v, red);
@@ -1753,6 +1766,10 @@ __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
       p.grads[p.off_gamma[j] + k] = v[0];
       p.grads[p.off_beta[j] + k] = v[1];
     }
+  }
+  if (p.sumsq) {
+    block_sum<1>(q, red);
+    if (threadIdx.x == 0) p.sumsq[blk] = q[0] + (p.has_ln ? v[0] * v[0] + v[1] * v[1] : 0.f);
   }
 }
 
@@ -1984,9 +2001,36 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
   return check_launch("fwd_out_kernel");
 }
 
+static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const float* table,
+                             const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                             void* workspace, const float* d_scores, float* grads, float* sumsq, void* stream);
+
 extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, const float* table,
                                  const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
                                  void* workspace, const float* d_scores, float* grads, void* stream) {
+  return dnn_backward_impl(desc, params, table, table_stats, n_rows, ldx, docids, M, workspace, d_scores, grads, nullptr,
+                           stream);
+}
+
+extern "C" int ultr_dnn_sumsq_count(const UltrDnnDesc* desc) {
+  if (check_desc(desc, "ultr_dnn_sumsq_count") != ULTR_OK) return -1;
+  const Layout L = make_layout(desc, 1);
+  int n = (3 * L.K[L.H] + 1 + 63) / 64;
+  for (int j = 0; j < L.H; ++j) n += L.K[j];
+  return n;
+}
+
+extern "C" int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const float* table,
+                                       const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                                       void* workspace, const float* d_scores, float* grads, float* sumsq, void* stream) {
+  ULTR_REQUIRE(sumsq, ULTR_EINVAL, "ultr_dnn_backward_sumsq: null sumsq");
+  return dnn_backward_impl(desc, params, table, table_stats, n_rows, ldx, docids, M, workspace, d_scores, grads, sumsq,
+                           stream);
+}
+
+static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const float* table,
+                             const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
+                             void* workspace, const float* d_scores, float* grads, float* sumsq, void* stream) {
   int rc = common_checks("ultr_dnn_backward", desc, params, table, table_stats, n_rows, ldx, docids, M, workspace);
   if (rc) return rc;
   ULTR_REQUIRE(d_scores && grads && ((uintptr_t)grads & 15) == 0, ULTR_EINVAL, "ultr_dnn_backward: bad d_scores/grads");
@@ -2181,6 +2225,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
   }
   f.params = params; f.grads = grads; f.has_ln = has_ln;
   f.outpart = ws + L.outpart; f.out_blocks = L.out_blocks; f.Kout = L.K[H];
+  f.sumsq = sumsq;
   {
     ultr::ProfScope prof_("finalize_kernel", st);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(start + (3 * L.K[H] + 1 + 63) / 64)), dim3(kThreads), 0, st, f);

@@ -79,26 +79,57 @@ __global__ void __launch_bounds__(kOptThreads) gnorm_partial_kernel(const float*
   if (threadIdx.x == 0) ws[8 + blockIdx.x] = acc[0];
 }
 
+// Options of the fused optimiser tail (ultr_clip_adagrad3); all nullable.
+struct TailOpts {
+  const float* sumsq; int n_sumsq; long long n_covered;  // sum-of-squares partials of grads[0, n_covered) (raw, l2 == 0)
+  const float* pub_src; float* pub_dst; int pub_n;       // results row copied out (pinned host memory) by workgroup 0
+};
+
 __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __restrict__ theta, float* __restrict__ accum,
                                                                     const float* __restrict__ grads, long long n,
                                                                     const float* __restrict__ denom, float scale_const,
                                                                     float l2, float clip_norm, float lr, int strategy,
                                                                     int n_partials, float* __restrict__ out_norm,
-                                                                    const float* __restrict__ ws) {
+                                                                    const float* __restrict__ ws, TailOpts o,
+                                                                    SmallGroup rider) {
   __shared__ float red[4];
+  if (rider.n > 0 && blockIdx.x == gridDim.x - 1) {  // the extra block updates the small group completely
+    clip_adagrad_small(rider.theta, rider.accum, rider.grads, rider.n, rider.denom, rider.scale_const, rider.l2,
+                       rider.clip_norm, rider.lr, rider.strategy, rider.out_norm);
+    // its norm goes out directly: workgroup 0 publishes the row at the same time and skips this entry
+    const long long idx = rider.out_norm && o.pub_n > 0 ? rider.out_norm - o.pub_src : -1;
+    if (threadIdx.x == 0 && idx >= 0 && idx < o.pub_n) o.pub_dst[idx] = rider.out_norm[0];
+    return;
+  }
+  const float sc = eff_scale(denom, scale_const);
+  const long long nblk = gridDim.x - (rider.n > 0 ? 1 : 0);
   // every block reduces the same partials in the same (fixed) order, so all blocks see one norm
   float ssq[1] = {0.f};
-  for (int p = threadIdx.x; p < n_partials; p += blockDim.x) ssq[0] += ws[8 + p];
-  block_sum<1>(ssq, red);
-  const float nrm = sqrtf(ssq[0]);
+  float nrm;
+  if (o.sumsq) {  // partials of the RAW gradient (the backward pass left them): ||g sc|| = |sc| ||g||
+    for (int p = threadIdx.x; p < o.n_sumsq; p += blockDim.x) ssq[0] += o.sumsq[p];
+    for (long long i = o.n_covered + threadIdx.x; i < n; i += blockDim.x) ssq[0] += grads[i] * grads[i];
+    block_sum<1>(ssq, red);
+    nrm = fabsf(sc) * sqrtf(ssq[0]);
+  } else {
+    for (int p = threadIdx.x; p < n_partials; p += blockDim.x) ssq[0] += ws[8 + p];
+    block_sum<1>(ssq, red);
+    nrm = sqrtf(ssq[0]);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
-  const float sc = eff_scale(denom, scale_const);
+  if (blockIdx.x == 0 && o.pub_n > 0) {  // the step's results row, straight into the caller's (pinned host) buffer
+    for (int i = threadIdx.x; i < o.pub_n; i += blockDim.x) {
+      const float* src = o.pub_src + i;
+      if (rider.n > 0 && src == rider.out_norm) continue;
+      o.pub_dst[i] = src == out_norm ? nrm : *src;
+    }
+  }
   const float f = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
   const long long n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(grads);
   float4* t4 = reinterpret_cast<float4*>(theta);
   float4* a4 = reinterpret_cast<float4*>(accum);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += nblk * blockDim.x) {
     const float4 g = g4[i];
     float4 t = t4[i];
     float gv[4] = {g.x, g.y, g.z, g.w};
@@ -146,13 +177,14 @@ using namespace ultr;
 
 static int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom,
                              float scale_const, float l2, float clip_norm, float lr, int strategy, float* out_norm,
-                             float* ws, const SmallGroup& rider, void* stream) {
+                             float* ws, const SmallGroup& rider, TailOpts o, void* stream) {
   ULTR_REQUIRE(theta && grads && n > 0, ULTR_EINVAL, "ultr_clip_adagrad: bad argument");
   ULTR_REQUIRE(strategy == ULTR_OPT_ADAGRAD || strategy == ULTR_OPT_SGD, ULTR_EINVAL,
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
   if (n <= 4096) {
-    ULTR_REQUIRE(rider.n == 0, ULTR_EINVAL, "ultr_clip_adagrad2: the main group must have more than 4096 parameters");
+    ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0, ULTR_EINVAL,
+                 "ultr_clip_adagrad: the fused options need a main group of more than 4096 parameters");
     {
       ultr::ProfScope prof_("clip_adagrad_small_kernel", as_stream(stream));
       hipLaunchKernelGGL(clip_adagrad_small_kernel, dim3(1), dim3(kOptThreads), 0, as_stream(stream), theta, acc, grads,
@@ -163,20 +195,29 @@ static int clip_adagrad_impl(float* theta, float* acc, const float* grads, long 
   ULTR_REQUIRE(ws, ULTR_EINVAL, "ultr_clip_adagrad: workspace required");
   ULTR_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grads % 16 == 0) && (!acc || (uintptr_t)acc % 16 == 0),
                ULTR_EINVAL, "ultr_clip_adagrad: buffers must be 16-byte aligned");
+  if (l2 != 0.f) o.sumsq = nullptr;  // the partials are of the raw gradient: with an l2 term the norm pass runs
+  ULTR_REQUIRE(!o.sumsq || (o.n_sumsq > 0 && o.n_covered >= 0 && o.n_covered <= n && n - o.n_covered <= 65536), ULTR_EINVAL,
+               "ultr_clip_adagrad3: bad sum-of-squares partials (n_sumsq=%d n_covered=%lld)", o.n_sumsq, o.n_covered);
+  ULTR_REQUIRE(o.pub_n == 0 || (o.pub_src && o.pub_dst && o.pub_n > 0), ULTR_EINVAL, "ultr_clip_adagrad3: bad publish range");
   long long blocks = cdiv(n >> 2, kOptThreads);
   if (blocks > kOptMaxBlocks) blocks = kOptMaxBlocks;
   if (blocks < 1) blocks = 1;
-  {
-    ultr::ProfScope prof_("gnorm_partial_kernel", as_stream(stream));
-    hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)(blocks + (rider.n > 0 ? 1 : 0))), dim3(kOptThreads), 0,
-                     as_stream(stream), theta, grads, n, denom, scale_const, l2, ws, rider);
+  SmallGroup none{};
+  if (!o.sumsq) {
+    {
+      ultr::ProfScope prof_("gnorm_partial_kernel", as_stream(stream));
+      hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)(blocks + (rider.n > 0 ? 1 : 0))), dim3(kOptThreads), 0,
+                       as_stream(stream), theta, grads, n, denom, scale_const, l2, ws, rider);
+    }
+    int rc = check_launch("gnorm_partial_kernel");
+    if (rc) return rc;
   }
-  int rc = check_launch("gnorm_partial_kernel");
-  if (rc) return rc;
+  const SmallGroup& apply_rider = o.sumsq ? rider : none;  // no norm launch: the small group rides with the update
   {
     ultr::ProfScope prof_("adagrad_apply_kernel", as_stream(stream));
-    hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)blocks), dim3(kOptThreads), 0, as_stream(stream), theta, acc,
-                     grads, n, denom, scale_const, l2, clip_norm, lr, strategy, (int)blocks, out_norm, ws);
+    hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)(blocks + (apply_rider.n > 0 ? 1 : 0))), dim3(kOptThreads), 0,
+                     as_stream(stream), theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, (int)blocks,
+                     out_norm, ws, o, apply_rider);
   }
   return check_launch("adagrad_apply_kernel");
 }
@@ -185,7 +226,7 @@ extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, l
                                  float scale_const, float l2, float clip_norm, float lr, int strategy,
                                  float* out_norm, float* ws, void* stream) {
   SmallGroup none{};
-  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, none, stream);
+  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, none, TailOpts{}, stream);
 }
 
 extern "C" int ultr_clip_adagrad2(float* theta, float* acc, const float* grads, long long n, const float* denom,
@@ -196,5 +237,21 @@ extern "C" int ultr_clip_adagrad2(float* theta, float* acc, const float* grads, 
   ULTR_REQUIRE(theta_s && grads_s && n_s > 0 && n_s <= 4096, ULTR_EINVAL, "ultr_clip_adagrad2: small group needs 1..4096 parameters");
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc_s, ULTR_EINVAL, "ultr_clip_adagrad2: Adagrad needs an accumulator");
   SmallGroup r{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
-  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, stream);
+  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, TailOpts{}, stream);
+}
+
+extern "C" int ultr_clip_adagrad3(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                                  float scale_const, float l2, float clip_norm, float lr, int strategy,
+                                  float* out_norm, float* ws, float* theta_s, float* acc_s, const float* grads_s,
+                                  int n_s, const float* denom_s, float scale_const_s, float l2_s, float clip_norm_s,
+                                  float lr_s, float* out_norm_s, const float* sumsq, int n_sumsq, long long n_covered,
+                                  const float* publish_src, float* publish_dst, int publish_n, void* stream) {
+  SmallGroup r{};
+  if (theta_s) {
+    ULTR_REQUIRE(grads_s && n_s > 0 && n_s <= 4096, ULTR_EINVAL, "ultr_clip_adagrad3: small group needs 1..4096 parameters");
+    ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc_s, ULTR_EINVAL, "ultr_clip_adagrad3: Adagrad needs an accumulator");
+    r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
+  }
+  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n};
+  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream);
 }

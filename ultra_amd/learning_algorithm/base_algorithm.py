@@ -16,6 +16,8 @@ N*B lists.
 """
 from abc import ABC, abstractmethod
 
+import ctypes
+
 import numpy as np
 import os
 import torch
@@ -222,6 +224,8 @@ class BaseAlgorithm(ABC):
         tb['list_weights'] = torch.empty(B, dtype=torch.float32, device=dev)
         tb['loss_ws'] = torch.zeros(_lib.lib().ultr_loss_workspace_floats(B, L), dtype=torch.float32, device=dev)
         tb['met_ws'] = dev_metrics.metrics_workspace(B, self.train_plan, dev)
+        tb['sumsq'] = torch.zeros(self.model.sumsq_count(), dtype=torch.float32, device=dev)
+        tb['host_dev'] = None  # device-side addresses of the pinned result slots, looked up on first use
         n_host = self.n_stats + n_met + self.N_LOCAL
         tb['host'] = torch.zeros((64, n_host), dtype=torch.float32).pin_memory()
         tb['events'] = [None] * 64
@@ -254,12 +258,33 @@ class BaseAlgorithm(ABC):
                                   tb['list_weights'] if weighted else None, tb['metrics'], tb['met_ws'], u,
                                   deferred=deferred)
 
-    def _publish(self, tb):
+    # ULTR_FUSED_TAIL=0: norm pass and result copy as launches of their own
+    fused_tail = os.environ.get('ULTR_FUSED_TAIL', '1') != '0'
+
+    def _next_slot(self, tb):
+        return 0 if tb['fixed_slot'] else tb['slot']
+
+    def _arm_tail(self, tb):
+        """Options for ultr_clip_adagrad3: norm partials left by the backward pass, and the results row written
+        straight into the pinned host slot by the update launch."""
+        if not self.fused_tail:
+            return None
+        tail = {'sumsq': tb['sumsq'] if tb.get('sumsq_valid') else None, 'n_covered': self.n_params}
+        if tb['host_dev'] is None:
+            base = _lib.host_device_ptr(tb['host'])
+            tb['host_dev'] = base.value if base is not None else 0
+        if tb['host_dev']:
+            row = tb['host'].shape[1]
+            tail['pub'] = (tb['bucket'][self.n_total:], tb['host_dev'] + 4 * row * self._next_slot(tb), row)
+        return tail
+
+    def _publish(self, tb, copied=False):
         """Async copy of [stats | metrics | local] to a pinned ring slot; returns fetch() -> numpy row."""
-        slot = 0 if tb['fixed_slot'] else tb['slot']
+        slot = self._next_slot(tb)
         tb['slot'] = (tb['slot'] + 1) % 64
         host = tb['host'][slot]
-        host.copy_(tb['bucket'][self.n_total:], non_blocking=True)
+        if not copied:
+            host.copy_(tb['bucket'][self.n_total:], non_blocking=True)
         capturing = torch.cuda.is_current_stream_capturing()
         ev = None
         if not capturing:
@@ -302,12 +327,15 @@ class BaseAlgorithm(ABC):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS)
+            tb['sumsq_valid'] = False
             self.model.backward(tb['d_scores'], tb['grads'])   # flat un-normalised gradient
             main.wait_stream(side)
         else:
             # the request is parked and carried by the backward pass inside one of its own launches
             self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS, deferred=self.ride_metrics)
-            self.model.backward(tb['d_scores'], tb['grads'])
+            # single GPU: the gradient is final after the backward pass, so its norm partials come out of it
+            tb['sumsq_valid'] = self.fused_tail and self.world == 1
+            self.model.backward(tb['d_scores'], tb['grads'], tb['sumsq'] if tb['sumsq_valid'] else None)
             if self.ride_metrics:
                 _lib.check(_lib.lib().ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
         self._pending = (tb, batch)
@@ -319,8 +347,10 @@ class BaseAlgorithm(ABC):
     def step_apply(self):
         """EM state, clip + Adagrad, publish; -> (loss, None, summary)."""
         tb, batch = self._pending
+        self._tail = self._arm_tail(tb)                        # consumed by the (last) clip + optimiser call of _update
         self._update(tb, batch)                                # EM state, clip + Adagrad
-        fetch = self._publish(tb)
+        fetch = self._publish(tb, copied=self._tail is not None and self._tail.get('published', False))
+        self._tail = None
         self.global_step.value += 1
         n_stats, n_met, world = self.n_stats, self.train_plan.n_out, float(self.world)
         tags = self.train_plan.tags(self.WEIGHTED_METRICS)
@@ -366,6 +396,9 @@ class BaseAlgorithm(ABC):
 
     # ---- optimiser helper --------------------------------------------------------------------------
     def _clip_adagrad(self, theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, out_norm):
+        tail = getattr(self, '_tail', None)
+        if tail is not None and n > 4096:
+            return self._clip_adagrad3((theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, out_norm), None, tail)
         _lib.check(_lib.lib().ultr_clip_adagrad(
             _lib.ptr(theta), _lib.ptr(acc), _lib.ptr(grads), int(n), _lib.ptr(denom), float(scale_const), float(l2),
             float(clip_norm), float(lr), self.strategy, _lib.ptr(out_norm), _lib.ptr(self.opt_ws),
@@ -378,12 +411,35 @@ class BaseAlgorithm(ABC):
             self._clip_adagrad(*small)
             self._clip_adagrad(*main)
             return
+        tail = getattr(self, '_tail', None)
+        if tail is not None:
+            return self._clip_adagrad3(main, small, tail)
         (th, ac, gr, n, den, sc, l2, clip, lr, out), (ths, acs, grs, ns, dens, scs, l2s, clips, lrs, outs) = main, small
         _lib.check(_lib.lib().ultr_clip_adagrad2(
             _lib.ptr(th), _lib.ptr(ac), _lib.ptr(gr), int(n), _lib.ptr(den), float(sc), float(l2), float(clip), float(lr),
             self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
             _lib.ptr(ths), _lib.ptr(acs), _lib.ptr(grs), int(ns), _lib.ptr(dens), float(scs), float(l2s), float(clips),
             float(lrs), _lib.ptr(outs), _lib.current_stream()), 'ultr_clip_adagrad2')
+
+    def _clip_adagrad3(self, main, small, tail):
+        """The fused tail of the step (ultr_clip_adagrad3): optional small group, norm partials from the backward
+        pass instead of a norm launch, results row written to the pinned host slot by the update launch."""
+        th, ac, gr, n, den, sc, l2, clip, lr, out = main
+        ths, acs, grs, ns, dens, scs, l2s, clips, lrs, outs = small if small is not None else (None,) * 4 + (None, 1.0, 0.0, 0.0, 0.0, None)
+        sumsq = tail.get('sumsq')
+        if sumsq is not None and (gr.data_ptr() != self._train_bufs['grads'].data_ptr() or n < tail['n_covered']):
+            sumsq = None  # the partials describe the step's flat gradient buffer only
+        pub = tail.get('pub')
+        _lib.check(_lib.lib().ultr_clip_adagrad3(
+            _lib.ptr(th), _lib.ptr(ac), _lib.ptr(gr), int(n), _lib.ptr(den), float(sc), float(l2), float(clip), float(lr),
+            self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
+            _lib.ptr(ths), _lib.ptr(acs), _lib.ptr(grs), int(ns or 0), _lib.ptr(dens), float(scs), float(l2s), float(clips),
+            float(lrs), _lib.ptr(outs),
+            _lib.ptr(sumsq), int(sumsq.numel()) if sumsq is not None else 0, int(tail['n_covered']),
+            _lib.ptr(pub[0]) if pub else None, ctypes.c_void_p(pub[1]) if pub else None, int(pub[2]) if pub else 0,
+            _lib.current_stream()), 'ultr_clip_adagrad3')
+        if pub:
+            tail['published'] = True
 
     # ---- checkpoint state ---------------------------------------------------------------------------
     def state_dict(self):

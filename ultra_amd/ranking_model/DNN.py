@@ -177,14 +177,24 @@ class DNN(BaseRankingModel):
         self._last = (table, table_stats, int(n_rows), docids_lb, M, ws)
         return scores
 
-    def backward(self, d_scores_lb, grads):
-        """grads[:n_params] = d(sum d_scores*scores)/d params for the LAST forward_lists call."""
+    def backward(self, d_scores_lb, grads, sumsq=None):
+        """grads[:n_params] = d(sum d_scores*scores)/d params for the LAST forward_lists call.  sumsq (optional,
+        ``sumsq_count()`` floats) receives partial sums of squares of that gradient (``ultr_dnn_backward_sumsq``)."""
         table, table_stats, n_rows, docids_lb, M, ws = self._last
+        if sumsq is not None:
+            _lib.check(_lib.lib().ultr_dnn_backward_sumsq(
+                self.desc, _lib.ptr(self.params), _lib.ptr(table), _lib.ptr(table_stats), n_rows, int(table.stride(0)),
+                _lib.ptr(docids_lb), M, _lib.ptr(ws), _lib.ptr(d_scores_lb), _lib.ptr(grads), _lib.ptr(sumsq),
+                _lib.current_stream()), 'ultr_dnn_backward_sumsq')
+            return grads
         _lib.check(_lib.lib().ultr_dnn_backward(
             self.desc, _lib.ptr(self.params), _lib.ptr(table), _lib.ptr(table_stats), n_rows, int(table.stride(0)),
             _lib.ptr(docids_lb), M, _lib.ptr(ws), _lib.ptr(d_scores_lb), _lib.ptr(grads), _lib.current_stream()),
             'ultr_dnn_backward')
         return grads
+
+    def sumsq_count(self):
+        return int(_lib.lib().ultr_dnn_sumsq_count(self.desc))
 
     def build(self, input_list, noisy_params=None, noise_rate=0.05, is_training=False, **kwargs):
         """Reference API (DNN.py:48-96): list of [B, F] feature tensors -> list of [B, 1] scores."""
