@@ -432,6 +432,51 @@ def test_clip_adagrad(L, n, strategy, clip, l2):
     assert relerr(th.cpu().numpy(), want_t) < 1e-6
 
 
+@pytest.mark.parametrize('with_small,with_sumsq,with_publish', [(True, True, True), (False, True, False),
+                                                                (True, False, True), (False, False, True)])
+def test_clip_adagrad3_fused_tail(L, with_small, with_sumsq, with_publish):
+    """ultr_clip_adagrad3 against two plain ultr_clip_adagrad calls: norm partials in place of the norm pass, the small
+    group riding along, the results row published by the update launch (here into device memory)."""
+    rng = np.random.RandomState(5)
+    n, n_cov, ns = 50000 + 64, 50000, 11
+    theta, acc, g = rng.normal(size=n), rng.uniform(0.1, 1.0, size=n), rng.normal(scale=0.01, size=n)
+    ths, acs, gs = rng.normal(size=ns), rng.uniform(0.1, 1.0, size=ns), rng.normal(size=ns)
+    row = torch.arange(32, dtype=torch.float32, device='cuda')  # results row: [.. | norm (20) | small norm (21) | ..]
+    dn, dns = dev([7.5], torch.float32), dev([3.0], torch.float32)
+
+    def fresh():
+        return [dev(x, torch.float32) for x in (theta, acc, g, ths, acs, gs)]
+    # reference: the plain entry point, one call per group
+    th0, ac0, g0, ths0, acs0, gs0 = fresh()
+    n0, n0s = torch.zeros(1, device='cuda'), torch.zeros(1, device='cuda')
+    ws = torch.zeros(2048, device='cuda')
+    L.check(L.lib().ultr_clip_adagrad(L.ptr(th0), L.ptr(ac0), L.ptr(g0), n, L.ptr(dn), 2.0, 0.0, 1.5, 0.05, 0,
+                                      L.ptr(n0), L.ptr(ws), stream(L)), 'opt')
+    L.check(L.lib().ultr_clip_adagrad(L.ptr(ths0), L.ptr(acs0), L.ptr(gs0), ns, L.ptr(dns), 1.0, 0.0, 0.7, 0.01, 0,
+                                      L.ptr(n0s), L.ptr(ws), stream(L)), 'opt')
+    th1, ac1, g1, ths1, acs1, gs1 = fresh()
+    parts = g1[:n_cov].double().view(50, -1).pow(2).sum(1).float().contiguous()  # 50 partial sums of squares
+    dst = torch.full((32,), -5.0, device='cuda')
+    small = [L.ptr(ths1), L.ptr(acs1), L.ptr(gs1), ns, L.ptr(dns), 1.0, 0.0, 0.7, 0.01, L.ptr(row[21:22])] if with_small \
+        else [None, None, None, 0, None, 1.0, 0.0, 0.0, 0.0, None]
+    L.check(L.lib().ultr_clip_adagrad3(
+        L.ptr(th1), L.ptr(ac1), L.ptr(g1), n, L.ptr(dn), 2.0, 0.0, 1.5, 0.05, 0, L.ptr(row[20:21]), L.ptr(ws), *small,
+        L.ptr(parts) if with_sumsq else None, 50 if with_sumsq else 0, n_cov,
+        L.ptr(row) if with_publish else None, L.ptr(dst) if with_publish else None, 32 if with_publish else 0,
+        stream(L)), 'opt3')
+    torch.cuda.synchronize()
+    assert relerr(th1.cpu().numpy(), th0.cpu().numpy()) < 1e-6 and relerr(ac1.cpu().numpy(), ac0.cpu().numpy()) < 1e-6
+    assert abs(row[20].item() - n0.item()) < RTOL * n0.item()
+    if with_small:
+        assert relerr(ths1.cpu().numpy(), ths0.cpu().numpy()) < 1e-6
+        assert abs(row[21].item() - n0s.item()) < RTOL * n0s.item()
+    if with_publish:
+        want = row.clone()
+        assert torch.equal(dst, want), (dst, want)  # the fresh norms included
+    else:
+        assert (dst == -5.0).all()
+
+
 # ------------------------------------------------------------------------------------------------
 # DNN forward / backward
 # ------------------------------------------------------------------------------------------------
@@ -509,6 +554,13 @@ def test_dnn_forward_backward(L, F, hidden, act, norm, B, Ls):
             used[o:o + ln] = True
     assert (flat[:model.desc.n_params][~used[:model.desc.n_params]] == 0).all()
     assert (flat[model.desc.n_params:] == 7.0).all()
+    # the same pass with norm partials (ultr_dnn_backward_sumsq): identical gradient, partials add up to its square norm
+    grads2 = torch.full((model.n_total,), 7.0, dtype=torch.float32, device='cuda')
+    sumsq = torch.full((model.sumsq_count(),), -1.0, dtype=torch.float32, device='cuda')
+    model.backward(dev(d_out).view(Ls, B), grads2, sumsq)
+    assert torch.equal(grads2, grads)
+    want_sq = float((flat[:model.desc.n_params].astype(np.float64) ** 2).sum())
+    assert abs(float(sumsq.double().sum()) - want_sq) <= 1e-5 * max(want_sq, 1e-30)
 
 
 def test_dnn_build_reference_api(L):
