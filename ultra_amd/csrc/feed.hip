@@ -112,9 +112,26 @@ __global__ void __launch_bounds__(256) assemble_slots_kernel(const int* __restri
                                                              int* __restrict__ out_list_idx, int* __restrict__ info) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  // A hipGraph replays frozen kernel arguments, so the per-step Philox counter may live in device
-  // memory: every block reads it here, and the LAST block to finish bumps it (all reads are done).
-  if (step_ctr) step += __hip_atomic_load(step_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // A hipGraph replays frozen kernel arguments, so the per-step Philox counter lives in device memory.  One thread
+  // per block reads it and hands it to the others through LDS; the bump needs no hand-off of data, only "every block
+  // has read the counter": the block arrives right after its read (the increment is made to depend on the value
+  // read, so it cannot overtake the read) and the last arriver bumps -- at the START of the kernel, off the critical
+  // path, with no release/acquire fence.
+  if (step_ctr) {
+    __shared__ unsigned int s_cur;
+    if (threadIdx.x == 0) {
+      const unsigned int cur = __hip_atomic_load(step_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_cur = cur;
+      unsigned int* arrive = reinterpret_cast<unsigned int*>(&info[3]);
+      const unsigned int t = __hip_atomic_fetch_add(arrive, 1u + (cur & 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == gridDim.x - 1) {
+        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    step += s_cur;
+  }
   if (b < B) {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const uint32_t slot = slot_base + (uint32_t)b;
@@ -174,10 +191,6 @@ __global__ void __launch_bounds__(256) assemble_slots_kernel(const int* __restri
         atomicAdd(&info[2], attempts);  // diagnostic: acceptance rate = B / total attempts
       }
     }
-  }
-  if (step_ctr) {
-    if (last_block_arrive(reinterpret_cast<unsigned int*>(&info[3]), gridDim.x) && threadIdx.x == 0)
-      __hip_atomic_fetch_add(step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
