@@ -124,6 +124,29 @@ def test_raw_data_toy_both_formats():
     assert sorted(a.labels[0]) == sorted(float(x) for x in b.labels[0])  # ULTRA lists are in SVMrank order
 
 
+def test_ranklist_output(tmp_path):
+    """TREC output (data_utils.py:383-501): descending score, ties in initial order, pads dropped, duplicates
+    removed and unmentioned positions appended."""
+    from ultra_amd.utils import generate_ranklist, generate_ranklist_by_scores, output_ranklist
+
+    class D(object):
+        qids = ['q1', 'q2']
+        dids = ['d0', 'd1', 'd2', 'd3', 'd4']
+        initial_list = [[0, 1, 2], [3, 4, -1]]
+    scores = [[0.5, 2.0, 0.5], [1.0, 3.0, 9.0]]
+    by_score = generate_ranklist_by_scores(D, scores)
+    assert by_score == {'q1': [('d1', 2.0), ('d0', 0.5), ('d2', 0.5)], 'q2': [('d4', 3.0), ('d3', 1.0)]}
+    assert generate_ranklist(D, [[2, 2, 0], [1, 0, 2]]) == {'q1': ['d2', 'd0', 'd1'], 'q2': ['d4', 'd3']}
+    with pytest.raises(ValueError):
+        generate_ranklist(D, [[0, 1, 2]])
+    with pytest.raises(ValueError):
+        generate_ranklist_by_scores(D, [[0.1, 0.2], [1.0, 2.0, 3.0]])
+    output_ranklist(D, scores, str(tmp_path) + '/', 'valid')
+    lines = open(str(tmp_path / 'valid.ranklist')).read().splitlines()
+    assert lines == ['q1 Q0 d1 1 2.0 Model', 'q1 Q0 d0 2 0.5 Model', 'q1 Q0 d2 3 0.5 Model',
+                     'q2 Q0 d4 1 3.0 Model', 'q2 Q0 d3 2 1.0 Model']
+
+
 def test_summary_merge():
     from ultra_amd.utils import merge_TFSummary, Summary, SummaryValue
     s1 = Summary(value=[SummaryValue('ndcg_10', 0.5), SummaryValue('mrr_3', 1.0)])

@@ -183,3 +183,52 @@ class Raw_data(object):
 
 def read_data(data_path, file_prefix, rank_cut=None):
     return Raw_data(data_path, file_prefix, rank_cut)
+
+
+# ---- ranked-list output (host side; reference: ultra/utils/data_utils.py:383-501) -------------------------------
+def _complete_order(order, n):
+    """De-duplicate `order` (first occurrence wins) and append the positions it never mentions, ascending."""
+    seen, out = set(), []
+    for idx in list(order) + list(range(n)):
+        if idx not in seen:
+            seen.add(idx)
+            out.append(idx)
+    return out
+
+
+def generate_ranklist(data, rerank_lists):
+    """qid -> document ids in the order given by positions into the initial list; pad entries dropped (:383-425)."""
+    if len(rerank_lists) != len(data.initial_list):
+        raise ValueError('The number of queries in rerank ranklists number must be equal to the initial list, %d != %d.'
+                         % (len(rerank_lists), len(data.initial_list)))
+    out = {}
+    for qid, initial, rerank in zip(data.qids, data.initial_list, rerank_lists):
+        if len(rerank) != len(initial):
+            raise ValueError('The number of docs in each rerank ranklists must be equal to the initial list, %d != %d.'
+                             % (len(rerank), len(initial)))
+        out[qid] = [data.dids[initial[idx]] for idx in _complete_order(rerank, len(rerank)) if initial[idx] >= 0]
+    return out
+
+
+def generate_ranklist_by_scores(data, rerank_scores):
+    """qid -> [(document id, score)] by descending score, ties in initial order; pad entries dropped (:428-477)."""
+    if len(rerank_scores) != len(data.initial_list):
+        raise ValueError('Rerank ranklists number must be equal to the initial list, %d != %d.'
+                         % (len(rerank_scores), len(data.initial_list)))
+    out = {}
+    for qid, initial, scores in zip(data.qids, data.initial_list, rerank_scores):
+        if len(scores) != len(initial):
+            raise ValueError('Rerank ranklists length must be equal to the gold list, %d != %d.'
+                             % (len(scores), len(initial)))
+        order = sorted(range(len(scores)), key=lambda k: scores[k], reverse=True)  # stable: ties keep initial order
+        out[qid] = [(data.dids[initial[idx]], scores[idx]) for idx in order if initial[idx] >= 0]
+    return out
+
+
+def output_ranklist(data, rerank_scores, output_path, file_name='test'):
+    """TREC run file `<output_path><file_name>.ranklist`: "qid Q0 did rank score Model" (:480-501)."""
+    ranked = generate_ranklist_by_scores(data, rerank_scores)
+    with open(output_path + file_name + '.ranklist', 'w') as fout:
+        for qid in data.qids:
+            for rank, (did, score) in enumerate(ranked[qid]):
+                fout.write('%s Q0 %s %d %s Model\n' % (qid, did, rank + 1, str(score)))
