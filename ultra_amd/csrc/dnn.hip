@@ -1916,7 +1916,12 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
   static const bool chain_on = [] { const char* e = getenv("ULTR_FWD_CHAIN"); return !(e && e[0] == '0'); }();
   size_t chain_smem = 0;
   int chain_ps = 0, chain_buf = 0;
-  if (chain_on && L.H >= 1 && L.K[0] <= 1024) {  // hidden widths are <= ULTR_MAX_WIDTH = 1024 (check_desc)
+  // The chain wins while its M / 16 workgroups are a few waves of the 256 CUs (measured, fwd kernels only, F = 136,
+  // [512, 256, 128]: M = 2560 41.6 us against 47.6; 10240 117 against 125; 20480 193 against 191; 40960 378 against 335):
+  // beyond that the per-layer kernels' 32-row tiles, which stream every weight half as often, are the better plan.
+  // ULTR_FWD_CHAIN=1 forces the chain at any size.
+  static const bool chain_force = [] { const char* e = getenv("ULTR_FWD_CHAIN"); return e && e[0] == '1'; }();
+  if (chain_on && (M <= 16384 || chain_force) && L.H >= 1 && L.K[0] <= 1024) {  // hidden widths are <= 1024 (check_desc)
     int maxw = L.K[0];
     for (int j = 0; j < L.H; ++j) maxw = L.N[j] > maxw ? L.N[j] : maxw;
     chain_ps = ((maxw + 31) & ~31) + 4;
