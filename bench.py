@@ -90,7 +90,8 @@ def build_world(cfg, args, device):
             GOLDEN, 'randomized_pbm_0.1_1.0_4_1.0.json')
     model = find_class(exp['learning_algorithm'])(data, exp, False)
     feed = find_class('ultra_amd.input_layer.ClickSimulationFeed')(
-        model, args.batch, 'click_model_json=%s,seed=2024' % os.path.join(GOLDEN, cfg['click']), None)
+        model, args.batch, 'click_model_json=%s,seed=2024,prefetch=%s' % (
+            os.path.join(GOLDEN, cfg['click']), 'true' if args.prefetch else 'false'), None)
     return data, exp, model, feed
 
 
@@ -163,6 +164,9 @@ def main():
     ap.add_argument('--force_collective', action='store_true',
                     help='single-GPU rehearsal of the multi-GPU launch path: a 1-rank RCCL group, all-reduce issued anyway')
     ap.add_argument('--algo_hparams', default='')
+    ap.add_argument('--prefetch', type=int, default=1,
+                    help='feed hparam prefetch: batch t+1 is assembled inside the last launch of step t (every step still '
+                         'assembles exactly one batch)')
     ap.add_argument('--cpu_seconds', type=float, default=12.0)
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')
@@ -327,7 +331,7 @@ def main():
                                    args.config, cfg['F'], cfg['L'], args.batch, cfg['algo'],
                                    'PBM' if 'pbm' in cfg['click'] else 'cascade', cfg['Q']),
                    'global_batch': args.batch * world, 'list_size': cfg['L'], 'parallelism': 'dp%d' % world,
-                   'launch': launch,
+                   'launch': launch, 'feed_prefetch': bool(args.prefetch),
                    'train_gflop_per_step_per_gpu': round(train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9, 3)},
         'final_loss': loss_value,
     }

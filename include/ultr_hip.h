@@ -123,6 +123,21 @@ int ultr_batch_assemble(const int* initial_list, const float* labels, int Q, int
                         int check_validation, int max_attempts, int n_rows, int* out_docids,
                         float* out_clicks, int* out_list_idx, int* info, void* stream);
 
+/* ultr_batch_assemble (mode 0) with the launch deferred -- a prefetching feed: the request is parked and the NEXT
+ * ultr_dnn_backward call of this host thread carries it as extra workgroups of its last launch, by which time
+ * nothing reads the current batch any more, so the output buffers may be the ones the current step is using
+ * (click_simulation_feed.py:107-162 assembles a batch per get_batch call; here the call for batch t+1 is made
+ * during step t).  The buffers must stay valid until the request has run.  ultr_batch_assemble_flush launches a parked request on its own; so does any later
+ * ultr_batch_assemble / ultr_batch_assemble_deferred call, so launch order is always call order. */
+int ultr_batch_assemble_deferred(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
+                                 int click_model, const double* exam, int n_exam, const double* click_prob,
+                                 int n_click_prob, unsigned long long seed, unsigned int step, unsigned int* step_ctr,
+                                 unsigned int slot_base, int check_validation, int max_attempts, int n_rows,
+                                 int* out_docids, float* out_clicks, int* out_list_idx, int* info, void* stream);
+int ultr_batch_assemble_flush(void* stream);
+/* Drops a parked request without running it (its output buffers are about to go away); returns 1 if there was one. */
+int ultr_batch_assemble_cancel(void);
+
 /* ---- DNN scorer (DNN.py:48-96 via base_algorithm.py:104-134) ---------------------------- */
 /* Bytes of workspace ultr_dnn_forward/backward need for M rows (M = L*B). */
 long long ultr_dnn_workspace_bytes(const UltrDnnDesc* desc, long long M);

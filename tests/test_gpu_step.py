@@ -315,3 +315,33 @@ def test_error_behaviour():
         find_class(exp['learning_algorithm'])(data, settings('DLA', 'loss_func=pairwise_loss'), False)
     with pytest.raises(ImportError):
         find_class('ultra_amd.ranking_model.NoSuchModel')
+
+
+def test_prefetching_feed_yields_the_same_batches_and_steps():
+    """prefetch=true assembles batch t+1 inside the last launch of step t's backward pass (into the same buffers);
+    the sequence of batches and the trained parameters must be exactly those of the plain feed."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(300, 10, 20, seed=21, pad_frac=0.1)
+    runs = []
+    for prefetch in ('false', 'true'):
+        exp = settings('DLA', feed_hparams='click_model_json=%s,seed=77,prefetch=%s' % (PBM, prefetch))
+        model, feed = make('DLA', data, exp, 96)
+        batches = []
+        for step in range(4):
+            feed_dict, info = feed.get_batch(data, True)
+            b = feed_dict[DEVICE_BATCH_KEY]
+            batches.append((b.docids.clone(), b.labels.clone(), list(x[0] for x in info['rank_list_idxs'])))
+            model.step(None, feed_dict, False)
+        # two calls with no step in between: the parked request is launched by the second call
+        f1, _ = feed.get_batch(data, True)
+        d1 = f1[DEVICE_BATCH_KEY].docids.clone()
+        f2, _ = feed.get_batch(data, True)
+        d2 = f2[DEVICE_BATCH_KEY].docids.clone()
+        runs.append((batches, d1, d2, model.model.params.clone(), model.prop_params.clone()))
+        del feed
+    (b0, d10, d20, p0, q0), (b1, d11, d21, p1, q1) = runs
+    for (da, ca, ia), (db, cb, ib) in zip(b0, b1):
+        assert torch.equal(da, db) and torch.equal(ca, cb) and ia == ib
+    assert not torch.equal(b0[0][0], b0[1][0])  # and they are different batches
+    assert torch.equal(d10, d11) and torch.equal(d20, d21) and not torch.equal(d10, d20)
+    assert torch.equal(p0, p1) and torch.equal(q0, q1)

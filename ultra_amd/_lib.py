@@ -62,6 +62,10 @@ SIGNATURES = {
     'ultr_click_cascade': (_I, [_P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),
     'ultr_batch_assemble': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _ULL, _U, _P, _U, _P, _I, _I,
                                  _I, _I, _I, _P, _P, _P, _P, _P]),
+    'ultr_batch_assemble_deferred': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _ULL, _U, _P, _U, _I, _I, _I, _P, _P,
+                                          _P, _P, _P]),
+    'ultr_batch_assemble_flush': (_I, [_P]),
+    'ultr_batch_assemble_cancel': (_I, []),
     'ultr_dnn_workspace_bytes': (_LL, [_DESC, _LL]),
     'ultr_dnn_forward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P]),
     'ultr_dnn_backward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P, _P]),

@@ -19,6 +19,7 @@
 //    layer 0 needs no dgrad GEMM at all), dgrad dh = dz W^T, then a row pass applies the
 //    LayerNorm backward and the activation derivative (from the stored activation output).
 #include "metrics_body.hpp"
+#include "feed_body.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -1686,9 +1687,8 @@ struct FinalizeArgs {
   float* sumsq;  // != NULL: [gridDim.x] sum of squares of what each workgroup stored into grads (norm partials)
 };
 
-__global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& p, const int blk) {
   __shared__ float red[8];
-  const int blk = blockIdx.x;
   if (blk >= p.row_start[p.H]) {  // output layer: column sums of the [out_blocks][3K+4] partial rows
     __shared__ float s_col[4][64];
     const int K = p.Kout, j = p.H;
@@ -1771,6 +1771,25 @@ __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) {
     block_sum<1>(q, red);
     if (threadIdx.x == 0) p.sumsq[blk] = q[0] + (p.has_ln ? v[0] * v[0] + v[1] * v[1] : 0.f);
   }
+}
+__global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) { finalize_body(p, blockIdx.x); }
+
+// The last launch of the backward pass can carry the assembly of the NEXT batch (ultr_batch_assemble_deferred): by
+// then nothing reads the current batch any more (the metrics rode with layer 0's weight gradients), so the feed
+// kernel's 10 us of Philox + rejection-sampling latency runs under the slab reduction instead of opening the next step.
+// Rider workgroups first (the longer pole), padded to a multiple of 8.
+struct FinalizeRiderArgs {
+  FinalizeArgs f;
+  AssembleArgs a;
+  int a_blocks, a_pad;
+};
+__global__ void __launch_bounds__(kThreads) finalize_rider_kernel(FinalizeRiderArgs p) {
+  const int id = blockIdx.x;
+  if (id >= p.a_pad) {
+    finalize_body(p.f, id - p.a_pad);
+    return;
+  }
+  if (id < p.a_blocks) assemble_slots_body(p.a, id, p.a_blocks);
 }
 
 }  // namespace ultr
@@ -2231,9 +2250,21 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   f.params = params; f.grads = grads; f.has_ln = has_ln;
   f.outpart = ws + L.outpart; f.out_blocks = L.out_blocks; f.Kout = L.K[H];
   f.sumsq = sumsq;
+  const unsigned fblocks = (unsigned)(start + (3 * L.K[H] + 1 + 63) / 64);
+  if (g_pending_assemble.on && g_pending_assemble.nblocks <= 4096) {
+    FinalizeRiderArgs fr{};
+    fr.f = f; fr.a = g_pending_assemble.a;
+    fr.a_blocks = (int)g_pending_assemble.nblocks; fr.a_pad = (fr.a_blocks + 7) & ~7;
+    g_pending_assemble.on = false;
+    {
+      ultr::ProfScope prof_("finalize_rider_kernel", st);
+      hipLaunchKernelGGL(finalize_rider_kernel, dim3(fblocks + (unsigned)fr.a_pad), dim3(kThreads), 0, st, fr);
+    }
+    return check_launch("finalize_rider_kernel");
+  }
   {
     ultr::ProfScope prof_("finalize_kernel", st);
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(start + (3 * L.K[H] + 1 + 63) / 64)), dim3(kThreads), 0, st, f);
+    hipLaunchKernelGGL(finalize_kernel, dim3(fblocks), dim3(kThreads), 0, st, f);
   }
   return check_launch("finalize_kernel");
 }

@@ -1,24 +1,9 @@
 // Click simulation and batch assembly on the device.
 // Reference: ultra/utils/click_models.py:86-116 (PBM), :204-241 (cascade);
 //            ultra/input_layer/click_simulation_feed.py:75-162 (get_batch).
-#include "common.hpp"
+#include "feed_body.hpp"
 
 namespace ultr {
-
-struct ClickTables {
-  const double* exam;
-  int n_exam;
-  const double* click_prob;
-  int n_cp;
-};
-
-// click probability of (rank, label) in float64, click_models.py:105-116
-__device__ __forceinline__ double click_threshold(const ClickTables& t, int rank, float label) {
-  int rel = label > 0.f ? (int)label : 0;           // int() truncation, negatives -> 0
-  rel = rel < t.n_cp ? rel : t.n_cp - 1;            // beyond the table -> last entry
-  const int r = rank < t.n_exam ? rank : t.n_exam - 1;
-  return t.exam[r] * t.click_prob[rel];
-}
 
 // draw d of the Philox stream (c0, c1, *, c3): words (2d, 2d+1) of the block sequence
 struct PhiloxDraws {
@@ -99,100 +84,7 @@ __device__ __forceinline__ void emit_slot(int slot, int i, unsigned long long ma
   out_list_idx[slot] = i;
 }
 
-// mode 0: one WAVE per slot (lane r = rank r), own Philox stream, bounded retry loop.  A thread-per-slot
-// loop would chain ~2.5 attempts x L dependent gathers; here one attempt is one round trip.
-__global__ void __launch_bounds__(256) assemble_slots_kernel(const int* __restrict__ initial_list,
-                                                             const float* __restrict__ labels, int Q, int Lmax, int L,
-                                                             int B, int click_model, ClickTables t,
-                                                             unsigned long long seed, unsigned int step,
-                                                             unsigned int* step_ctr,
-                                                             unsigned int slot_base, int check_validation,
-                                                             int max_attempts, int n_rows, int* __restrict__ out_docids,
-                                                             float* __restrict__ out_clicks,
-                                                             int* __restrict__ out_list_idx, int* __restrict__ info) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  // A hipGraph replays frozen kernel arguments, so the per-step Philox counter lives in device memory.  One thread
-  // per block reads it and hands it to the others through LDS; the bump needs no hand-off of data, only "every block
-  // has read the counter": the block arrives right after its read (the increment is made to depend on the value
-  // read, so it cannot overtake the read) and the last arriver bumps -- at the START of the kernel, off the critical
-  // path, with no release/acquire fence.
-  if (step_ctr) {
-    __shared__ unsigned int s_cur;
-    if (threadIdx.x == 0) {
-      const unsigned int cur = __hip_atomic_load(step_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_cur = cur;
-      unsigned int* arrive = reinterpret_cast<unsigned int*>(&info[3]);
-      const unsigned int t = __hip_atomic_fetch_add(arrive, 1u + (cur & 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == gridDim.x - 1) {
-        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();
-    step += s_cur;
-  }
-  if (b < B) {
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const uint32_t slot = slot_base + (uint32_t)b;
-    const unsigned long long lmask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
-    // Rejection sampling is a serial chain of dependent loads per attempt (list row -> labels -> click tables),
-    // and the step waits for the unluckiest slot.  Attempts are independent Philox streams (keyed by the attempt
-    // index), so the wave evaluates G = 64 / P of them AT ONCE (P = lanes per attempt) and takes the first one
-    // the sequential rule would have taken: same draws, same result, one round of loads in >99 % of the slots.
-    const int P = L <= 16 ? 16 : L <= 32 ? 32 : 64, G = 64 / P;
-    const int ai = lane / P, pos = lane % P;
-    int i = 0, doc = -1, attempts = 0, gsel = 0;
-    float lab = 0.f;
-    unsigned long long mask = 0ull;
-    for (int a0 = 0; a0 < max_attempts; a0 += G) {
-      const int a = a0 + ai;
-      // draw 0 (words 0,1 of block 0) picks the list: int(random.random() * length) (:132)
-      const Philox4 b0 = philox4x32_10(slot, (uint32_t)a, 0u, step, k0, k1);
-      i = (int)(u53(b0.v[0], b0.v[1]) * (double)Q);
-      i = i < Q ? i : Q - 1;
-      bool c = false;
-      doc = -1;
-      lab = 0.f;
-      if (pos < L && a < max_attempts) {
-        doc = initial_list[(long long)i * Lmax + pos];
-        lab = doc < 0 ? 0.f : labels[(long long)i * Lmax + pos];  // :80-82
-        if (click_model == ULTR_CLICK_ORACLE) {
-          c = lab != 0.f;
-        } else {
-          const int d = 1 + pos;  // draws 1..L are the click draws (:87)
-          const Philox4 bd = philox4x32_10(slot, (uint32_t)a, (uint32_t)(d >> 1), step, k0, k1);
-          const double u = (d & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
-          c = u < click_threshold(t, pos, lab);
-        }
-      }
-      const unsigned long long bal = __ballot(c);
-      bool done = false;
-      for (int g = 0; g < G && !done; ++g) {  // wave-uniform: the first attempt of this round that is accepted
-        if (a0 + g >= max_attempts) break;
-        unsigned long long mg = (P == 64 ? bal : (bal >> (g * P))) & lmask;
-        if (click_model == ULTR_CLICK_CASCADE) mg &= (~mg + 1ull);  // only the first click counts
-        if (!check_validation || mg != 0ull || a0 + g == max_attempts - 1) {
-          done = true;
-          gsel = g;
-          mask = mg;
-          attempts = a0 + g + 1;
-        }
-      }
-      if (done) break;
-    }
-    if (ai == gsel && pos < L) {
-      out_docids[(long long)pos * B + b] = doc < 0 ? n_rows : doc;  // pad -> the zero row (:140-143)
-      float cv = ((mask >> pos) & 1ull) ? 1.f : 0.f;
-      if (click_model == ULTR_CLICK_ORACLE) cv = lab;
-      out_clicks[(long long)pos * B + b] = cv;
-      if (pos == 0) {
-        out_list_idx[b] = i;
-        atomicAdd(&info[2], attempts);  // diagnostic: acceptance rate = B / total attempts
-      }
-    }
-  }
-}
+__global__ void __launch_bounds__(256) assemble_slots_kernel(AssembleArgs a) { assemble_slots_body(a, blockIdx.x, gridDim.x); }
 
 // mode 1: a single workgroup consumes the supplied candidates IN ORDER (bit-exact with the
 // reference's sequential random.random() stream).  Every loop bound is block-uniform.
@@ -288,13 +180,21 @@ extern "C" int ultr_click_cascade(const float* labels, long long n, int L, const
                       stream);
 }
 
-extern "C" int ultr_batch_assemble(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
-                                   int click_model, const double* exam, int n_exam, const double* click_prob,
-                                   int n_click_prob, int mode, unsigned long long seed, unsigned int step,
-                                   unsigned int* step_ctr,
-                                   unsigned int slot_base, const double* uniforms, int n_cand, int slot_start,
-                                   int check_validation, int max_attempts, int n_rows, int* out_docids,
-                                   float* out_clicks, int* out_list_idx, int* info, void* stream) {
+namespace ultr {
+thread_local PendingAssemble g_pending_assemble = {};
+
+int launch_assemble_now(const AssembleArgs& a, unsigned nblocks, hipStream_t st) {
+  {
+    ultr::ProfScope prof_("assemble_slots_kernel", st);
+    hipLaunchKernelGGL(assemble_slots_kernel, dim3(nblocks), dim3(256), 0, st, a);
+  }
+  return check_launch("assemble_slots_kernel");
+}
+}  // namespace ultr
+
+static int assemble_checks(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B, int click_model,
+                           const double* exam, int n_exam, const double* click_prob, int n_click_prob,
+                           int* out_docids, float* out_clicks, int* out_list_idx, int* info) {
   ULTR_REQUIRE(initial_list && labels && exam && click_prob && out_docids && out_clicks && out_list_idx && info,
                ULTR_EINVAL, "ultr_batch_assemble: null pointer");
   ULTR_REQUIRE(Q > 0 && B > 0 && L > 0 && n_exam > 0 && n_click_prob > 0, ULTR_EINVAL,
@@ -306,16 +206,45 @@ extern "C" int ultr_batch_assemble(const int* initial_list, const float* labels,
   ULTR_REQUIRE(click_model == ULTR_CLICK_PBM || click_model == ULTR_CLICK_CASCADE || click_model == ULTR_CLICK_ORACLE,
                ULTR_EINVAL,
                "ultr_batch_assemble: click model %d is not on the device path", click_model);
+  return ULTR_OK;
+}
+
+static AssembleArgs assemble_args(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
+                                  int click_model, const double* exam, int n_exam, const double* click_prob,
+                                  int n_click_prob, unsigned long long seed, unsigned int step, unsigned int* step_ctr,
+                                  unsigned int slot_base, int check_validation, int max_attempts, int n_rows,
+                                  int* out_docids, float* out_clicks, int* out_list_idx, int* info) {
+  AssembleArgs a{};
+  a.initial_list = initial_list; a.labels = labels; a.Q = Q; a.Lmax = Lmax; a.L = L; a.B = B; a.click_model = click_model;
+  a.t = ClickTables{exam, n_exam, click_prob, n_click_prob};
+  a.seed = seed; a.step = step; a.step_ctr = step_ctr; a.slot_base = slot_base;
+  a.check_validation = check_validation; a.max_attempts = max_attempts; a.n_rows = n_rows;
+  a.out_docids = out_docids; a.out_clicks = out_clicks; a.out_list_idx = out_list_idx; a.info = info;
+  return a;
+}
+
+extern "C" int ultr_batch_assemble(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
+                                   int click_model, const double* exam, int n_exam, const double* click_prob,
+                                   int n_click_prob, int mode, unsigned long long seed, unsigned int step,
+                                   unsigned int* step_ctr,
+                                   unsigned int slot_base, const double* uniforms, int n_cand, int slot_start,
+                                   int check_validation, int max_attempts, int n_rows, int* out_docids,
+                                   float* out_clicks, int* out_list_idx, int* info, void* stream) {
+  int rc = assemble_checks(initial_list, labels, Q, Lmax, L, B, click_model, exam, n_exam, click_prob, n_click_prob,
+                           out_docids, out_clicks, out_list_idx, info);
+  if (rc) return rc;
+  if (g_pending_assemble.on) {  // a parked request nobody carried runs first, on its own: launch order is call order
+    g_pending_assemble.on = false;
+    rc = launch_assemble_now(g_pending_assemble.a, g_pending_assemble.nblocks, as_stream(stream));
+    if (rc) return rc;
+  }
   ClickTables t{exam, n_exam, click_prob, n_click_prob};
   if (mode == 0) {
     ULTR_REQUIRE(max_attempts >= 1, ULTR_EINVAL, "ultr_batch_assemble: max_attempts=%d", max_attempts);
-    {
-      ultr::ProfScope prof_("assemble_slots_kernel", as_stream(stream));
-      hipLaunchKernelGGL(assemble_slots_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream),
-                       initial_list, labels, Q, Lmax, L, B, click_model, t, seed, step, step_ctr, slot_base, check_validation,
-                       max_attempts, n_rows, out_docids, out_clicks, out_list_idx, info);
-    }
-    return check_launch("assemble_slots_kernel");
+    return launch_assemble_now(assemble_args(initial_list, labels, Q, Lmax, L, B, click_model, exam, n_exam, click_prob,
+                                             n_click_prob, seed, step, step_ctr, slot_base, check_validation,
+                                             max_attempts, n_rows, out_docids, out_clicks, out_list_idx, info),
+                               (unsigned)cdiv(B, 4), as_stream(stream));
   }
   ULTR_REQUIRE(mode == 1, ULTR_EINVAL, "ultr_batch_assemble: mode=%d", mode);
   ULTR_REQUIRE(uniforms && n_cand > 0 && slot_start >= 0 && slot_start < B, ULTR_EINVAL,
@@ -327,4 +256,39 @@ extern "C" int ultr_batch_assemble(const int* initial_list, const float* labels,
                      out_clicks, out_list_idx, info);
   }
   return check_launch("assemble_sequential_kernel");
+}
+
+extern "C" int ultr_batch_assemble_deferred(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
+                                            int click_model, const double* exam, int n_exam, const double* click_prob,
+                                            int n_click_prob, unsigned long long seed, unsigned int step,
+                                            unsigned int* step_ctr, unsigned int slot_base, int check_validation,
+                                            int max_attempts, int n_rows, int* out_docids, float* out_clicks,
+                                            int* out_list_idx, int* info, void* stream) {
+  int rc = assemble_checks(initial_list, labels, Q, Lmax, L, B, click_model, exam, n_exam, click_prob, n_click_prob,
+                           out_docids, out_clicks, out_list_idx, info);
+  if (rc) return rc;
+  ULTR_REQUIRE(max_attempts >= 1, ULTR_EINVAL, "ultr_batch_assemble_deferred: max_attempts=%d", max_attempts);
+  if (g_pending_assemble.on) {
+    g_pending_assemble.on = false;
+    rc = launch_assemble_now(g_pending_assemble.a, g_pending_assemble.nblocks, as_stream(stream));
+    if (rc) return rc;
+  }
+  g_pending_assemble.a = assemble_args(initial_list, labels, Q, Lmax, L, B, click_model, exam, n_exam, click_prob,
+                                       n_click_prob, seed, step, step_ctr, slot_base, check_validation, max_attempts,
+                                       n_rows, out_docids, out_clicks, out_list_idx, info);
+  g_pending_assemble.nblocks = (unsigned)cdiv(B, 4);
+  g_pending_assemble.on = true;
+  return ULTR_OK;
+}
+
+extern "C" int ultr_batch_assemble_flush(void* stream) {
+  if (!g_pending_assemble.on) return ULTR_OK;
+  g_pending_assemble.on = false;
+  return launch_assemble_now(g_pending_assemble.a, g_pending_assemble.nblocks, as_stream(stream));
+}
+
+extern "C" int ultr_batch_assemble_cancel(void) {
+  const int was = g_pending_assemble.on ? 1 : 0;
+  g_pending_assemble.on = false;
+  return was;
 }

@@ -37,7 +37,8 @@ class ClickSimulationFeed(BaseInputFeed):
             dynamic_bias_eta_change=0.0,     # eta increment for dynamic bias severity, 0 = off
             dynamic_bias_step_interval=1000,
             device_rng=True,                 # (new) False: consume Python's random stream, bit-exact
-            seed=0)                          # (new) Philox key of the device stream
+            seed=0,                          # (new) Philox key of the device stream
+            prefetch=False)                  # (new) assemble batch t+1 during the backward pass of step t
         print('Create simluated clicks feed')
         print(hparam_str)
         self.hparams.parse(hparam_str)
@@ -62,6 +63,15 @@ class ClickSimulationFeed(BaseInputFeed):
             model.step_ctr = self.step_ctr  # regression-EM draws its Bernoulli uniforms on the same counter
         self.info = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._out = {}
+        # prefetch: (data set, batch size, check_validation) the buffers were last filled / parked for
+        self._prefetched = None
+
+    def __del__(self):
+        try:
+            if self._prefetched is not None:
+                _lib.lib().ultr_batch_assemble_cancel()  # the parked request points into buffers that go away with us
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def _upload_tables(self):
         if self.click_model is None:
@@ -94,6 +104,17 @@ class ClickSimulationFeed(BaseInputFeed):
             parallel.slot_base(self.rank, B), _lib.ptr(uniforms), n_cand, slot_start, 1 if check_validation else 0,
             self.MAX_SAMPLE_ROUND_NUM, dd.n_rows, _lib.ptr(o['docids']), _lib.ptr(o['clicks']), _lib.ptr(o['idx']),
             _lib.ptr(self.info), _lib.current_stream()), 'ultr_batch_assemble')
+
+    def _assemble_deferred(self, dd, o, B, check_validation):
+        """Park the assembly of the NEXT batch: the backward pass of the coming step carries it inside its last
+        launch (``ultr_batch_assemble_deferred``); if no backward pass comes first, the next call launches it."""
+        _lib.check(_lib.lib().ultr_batch_assemble_deferred(
+            _lib.ptr(dd.initial_list), _lib.ptr(dd.labels), dd.Q, dd.Lmax, self.rank_list_size, B, self.kind,
+            _lib.ptr(self.exam), self.exam.numel(), _lib.ptr(self.click_prob), self.click_prob.numel(),
+            int(self.hparams.seed) & 0xFFFFFFFFFFFFFFFF, 0, _lib.ptr(self.step_ctr), parallel.slot_base(self.rank, B),
+            1 if check_validation else 0, self.MAX_SAMPLE_ROUND_NUM, dd.n_rows, _lib.ptr(o['docids']),
+            _lib.ptr(o['clicks']), _lib.ptr(o['idx']), _lib.ptr(self.info), _lib.current_stream()),
+            'ultr_batch_assemble_deferred')
 
     def _sample_python_stream(self, dd, o, B, check_validation):
         """Consume random.random() exactly like click_simulation_feed.py:131-137 (q2): per candidate one
@@ -135,7 +156,18 @@ class ClickSimulationFeed(BaseInputFeed):
         dd = DeviceDataset.of(data_set, self.device)
         B = self.batch_size
         o = self._buffers(B)
-        if self.hparams.device_rng:
+        if self.hparams.device_rng and self.hparams.prefetch and self.hparams.dynamic_bias_eta_change == 0:
+            # Prefetching feed: the batch returned now was assembled during the previous step's backward pass, into
+            # these same buffers (nothing reads a batch after the weight gradients of its step); this call only
+            # parks the request for the batch after it.  Host-side views of a batch (input_list, click_list, the
+            # per-position feed entries) must therefore be read before the step that follows this call.
+            key = (id(dd), B, bool(check_validation))
+            if self._prefetched != key:
+                _lib.lib().ultr_batch_assemble_cancel()  # a request parked for other arguments is dropped
+                self._assemble(dd, o, B, 0, check_validation=check_validation)
+            self._assemble_deferred(dd, o, B, check_validation)
+            self._prefetched = key
+        elif self.hparams.device_rng:
             self._assemble(dd, o, B, 0, check_validation=check_validation)
         else:
             self._sample_python_stream(dd, o, B, check_validation)
