@@ -227,7 +227,8 @@ def test_dla_loss_kernel(L, B, Ls, loss_func, prob, maxw):
     assert relerr(lw.cpu().numpy(), want_lw) < RTOL
 
 
-@pytest.mark.parametrize('B,Ls,loss_func', [(256, 10, 0), (777, 7, 0), (256, 10, 1)])
+@pytest.mark.parametrize('B,Ls,loss_func', [(256, 10, 0), (777, 7, 0), (256, 10, 1), (20000, 10, 0), (130, 16, 1),
+                                            (128, 24, 0), (96, 24, 1)])  # L <= 16: lane per (list, rank); beyond: thread per list
 def test_ipw_loss_kernel(L, B, Ls, loss_func):
     rng = np.random.RandomState(3)
     scores, clicks = _scores_clicks(rng, B, Ls)
@@ -258,7 +259,7 @@ def test_ipw_loss_kernel(L, B, Ls, loss_func):
     assert relerr(lw.cpu().numpy(), (pw_ref * np.clip(clicks, 0, 1)).mean(1)) < RTOL
 
 
-@pytest.mark.parametrize('B,Ls', [(256, 10), (1500, 6)])
+@pytest.mark.parametrize('B,Ls', [(256, 10), (1500, 6), (20000, 10), (100, 16), (128, 24)])  # as for IPW
 def test_rem_loss_kernel(L, B, Ls):
     rng = np.random.RandomState(9)
     scores, clicks = _scores_clicks(rng, B, Ls)
@@ -299,7 +300,7 @@ def test_rem_loss_kernel(L, B, Ls):
     assert not torch.equal(y1, y) and ((y1 == 0) | (y1 == 1)).all() and (y1 >= c).all()
 
 
-@pytest.mark.parametrize('B,Ls', [(256, 10), (900, 5), (64, 32)])
+@pytest.mark.parametrize('B,Ls', [(256, 10), (900, 5), (64, 32), (20000, 10), (333, 16)])  # short-list kernel: L <= 16
 def test_pd_loss_kernel(L, B, Ls):
     rng = np.random.RandomState(13)
     scores, clicks = _scores_clicks(rng, B, Ls)

@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 import torch
 import bench
 class A: pass
-args = A(); args.batch = 256; args.algo_hparams = ''
+args = A(); args.batch = 256; args.algo_hparams = ''; args.prefetch = 1
 cfg = bench.CONFIGS['mslr10k']
 dev = torch.device('cuda', 0)
 with contextlib.redirect_stdout(sys.stderr):

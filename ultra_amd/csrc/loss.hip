@@ -125,6 +125,64 @@ __global__ void __launch_bounds__(kLossThreads) ipw_loss_kernel(const float* __r
   finish_stats(s_acc, 2 + L, 2, ws, stats);
 }
 
+// IPW for short lists (L <= 16): one lane per (list, rank), 16 lists per block; the per-list softmax is a group
+// reduction over 16 lanes, the per-rank maxima meet by lane exchange.  Same arithmetic as ipw_loss_kernel.
+__global__ void __launch_bounds__(kLossThreads) ipw_loss_small_kernel(const float* __restrict__ scores,
+                                                                      const float* __restrict__ clicks,
+                                                                      const float* __restrict__ pw, int B, int L,
+                                                                      int loss_func, float* __restrict__ d_scores,
+                                                                      float* __restrict__ stats,
+                                                                      float* __restrict__ list_weights, float* ws) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & 15, li = tid >> 4;
+  const bool in_list = r < L;
+  float num = 0.f, den = 0.f, wmax = -INFINITY;
+  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
+    const long long b = b0 + li;
+    const bool live = in_list && b < B;
+    const long long e = (long long)r * B + (b < B ? b : 0);
+    const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f, w = live ? pw[e] : 0.f;
+    if (live) wmax = fmaxf(wmax, w);
+    const float lw = group_sum<16>(live ? w * fminf(fmaxf(c, 0.f), 1.f) : 0.f);
+    if (loss_func == ULTR_LOSS_SOFTMAX) {
+      const float m = group_max<16>(live ? o : -INFINITY);
+      const float se = group_sum<16>(live ? expf(o - m) : 0.f);
+      const float wl = live ? (c + 0.0000001f) * w : 0.f;
+      const float S = group_sum<16>(wl);
+      const float lse = m + logf(se);
+      if (live) {
+        num -= wl * (o - lse);
+        d_scores[e] = expf(o - lse) * S - wl;
+        den += r == 0 ? S : 0.f;
+      }
+    } else if (live) {
+      const float z = fminf(c, 1.f);
+      num += sig_ce(z, o) * w;
+      d_scores[e] = (sigmoidf_(o) - z) * w;
+      den += r == 0 ? 1.f : 0.f;
+    }
+    if (live && r == 0 && list_weights) list_weights[b] = lw / (float)L;
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  float o1, o2;
+  wmax = xor16_partner(wmax, &o1);
+  wmax = fmaxf(wmax, o1);
+  wmax = xor32_partner(wmax, &o2);
+  wmax = fmaxf(wmax, o2);
+  float* mine = s_part + wid * kMaxStat;
+  if (lane == 0) {
+    mine[0] = num;
+    mine[1] = den;
+  }
+  if (lane < L) mine[2 + lane] = wmax;
+  BlockStats bs{s_part};
+  bs.combine(s_acc, 2 + L, 2);
+  finish_stats(s_acc, 2 + L, 2, ws, stats);
+}
+
 __global__ void ipw_weights_kernel(const float* __restrict__ clicks, int B, int L, const float* __restrict__ ipw,
                                    int n_ipw, float* __restrict__ pw) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,16 +428,17 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(
   bs.combine(s_acc, 4 + 3 * L, 1 << 30);
   if (finish_stats(s_acc, 4 + 3 * L, 1 << 30, ws, stats)) {
     if (tid < L) stats[4 + tid] = s_tower[3][tid];
-    if (tid == 0) {  // chain through the tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l
-      float db = 0.f;
-      for (int l = 0; l < L; ++l) {
+    if (tid < 64) {  // chain through the tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l
+      float dpre = 0.f;  // one rank per lane, the bias gradient is their wave sum
+      if (tid < L) {
+        const int l = tid;
         const float dlogit = loss_func == ULTR_LOSS_SOFTMAX ? expf(s_tower[2][l]) * s_acc[3] - s_acc[4 + 2 * L + l]
                                                             : s_acc[4 + 2 * L + l];
-        const float dpre = dlogit * (s_tower[0][l] > 0.f ? 1.f : s_tower[1][l] + 1.f);
+        dpre = dlogit * (s_tower[0][l] > 0.f ? 1.f : s_tower[1][l] + 1.f);
         prop_grads[l] = dpre;
-        db += dpre;
       }
-      prop_grads[L] = db;
+      const float db = wave_sum(dpre);
+      if (tid == 0) prop_grads[L] = db;
     }
   }
 }
@@ -442,6 +501,86 @@ __global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
   bs.add(0, loss);
   bs.add(1, on ? 1.f : 0.f);
   bs.add(2 + 3 * L, dsum);
+  bs.combine(s_acc, 3 + 3 * L, 1 << 30);
+  if (finish_stats(s_acc, 3 + 3 * L, 1 << 30, ws, stats)) {
+    if (threadIdx.x == 0 && d_bias) d_bias[0] = s_acc[2 + 3 * L];  // un-normalised d loss / d sigmoid_prob_b
+  }
+}
+
+// Regression-EM for short lists (L <= 16): one lane per (list, rank), 16 lists per block -- the batch-256 step then
+// runs on 16 CUs with one pass of per-rank exchanges instead of one CU walking the ranks with 3 L wave reductions.
+// Same arithmetic and the same Philox words per (list, rank) as rem_loss_kernel.
+__global__ void __launch_bounds__(kLossThreads) rem_loss_small_kernel(
+    const float* __restrict__ scores, const float* __restrict__ clicks, int B, int L,
+    const float* __restrict__ propensity, const float* __restrict__ bias_ptr, const float* __restrict__ uniforms,
+    unsigned long long seed, unsigned int step, const unsigned int* step_ctr, unsigned int slot_base,
+    float* __restrict__ d_scores, float* __restrict__ ranker_labels, float* __restrict__ list_weights,
+    float* __restrict__ stats, float* d_bias, float* ws) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & 15, li = tid >> 4;
+  const bool in_list = r < L;
+  const float bias = bias_ptr ? bias_ptr[0] : 0.f;
+  const float p = in_list ? propensity[r] : 1.f;
+  if (step_ctr) step += step_ctr[0];  // device-resident step counter (read-only here), see feed.hip
+  float loss = 0.f, cnt = 0.f, dsum = 0.f, ms = 0.f, ys = 0.f, cs = 0.f;
+  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
+    const long long b = b0 + li;
+    const bool live = in_list && b < B;
+    const long long e = (long long)r * B + (b < B ? b : 0);
+    float lwt = 0.f;
+    if (live) {
+      const float x = scores[e] + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
+      const float c = clicks[e];
+      const float g = sigmoidf_(x);
+      const float den = 1.f - p * g;
+      const float p_e1_r0_c0 = p * (1.f - g) / den;  // :140-141
+      const float p_e0_r1_c0 = (1.f - p) * g / den;  // :142-143
+      const float p_r1 = c + (1.f - c) * p_e0_r1_c0;  // :147-148
+      float u;
+      if (uniforms) {
+        u = uniforms[e];
+      } else {
+        const Philox4 rnd = philox4x32_10(slot_base + (uint32_t)b, 0x52454Du, (uint32_t)(r >> 2), step, (uint32_t)seed,
+                                          (uint32_t)(seed >> 32));
+        u = u24(rnd.v[r & 3]);
+      }
+      float y = ceilf(p_r1 - u);  // get_bernoulli_sample (:39)
+      y = y > 0.f ? y : 0.f;      // ceil(-0.x) = -0 -> 0
+      loss += sig_ce(y, x);       // :159-165
+      const float d = g - y;
+      d_scores[e] = d;
+      dsum += d;
+      if (ranker_labels) ranker_labels[e] = y;
+      ms += c + (1.f - c) * p_e1_r0_c0;  // :153
+      ys += y;
+      cs += c;
+      lwt = fminf(fmaxf(c, 0.f), 1.f) / p;  // propensity_weights = 1/propensity (:176)
+      cnt += r == 0 ? 1.f : 0.f;
+    }
+    const float lw = group_sum<16>(lwt);
+    if (live && r == 0 && list_weights) list_weights[b] = lw / (float)L;
+  }
+  loss = wave_sum(loss);
+  cnt = wave_sum(cnt);
+  dsum = wave_sum(dsum);
+  float o1, o2;
+  ms = xor16_partner(ms, &o1); ms += o1; ms = xor32_partner(ms, &o2) + o2;
+  ys = xor16_partner(ys, &o1); ys += o1; ys = xor32_partner(ys, &o2) + o2;
+  cs = xor16_partner(cs, &o1); cs += o1; cs = xor32_partner(cs, &o2) + o2;
+  float* mine = s_part + wid * kMaxStat;
+  if (lane == 0) {
+    mine[0] = loss;
+    mine[1] = cnt;
+    mine[2 + 3 * L] = dsum;
+  }
+  if (lane < L) {
+    mine[2 + lane] = ms;
+    mine[2 + L + lane] = ys;
+    mine[2 + 2 * L + lane] = cs;
+  }
+  BlockStats bs{s_part};
   bs.combine(s_acc, 3 + 3 * L, 1 << 30);
   if (finish_stats(s_acc, 3 + 3 * L, 1 << 30, ws, stats)) {
     if (threadIdx.x == 0 && d_bias) d_bias[0] = s_acc[2 + 3 * L];  // un-normalised d loss / d sigmoid_prob_b
@@ -535,11 +674,87 @@ __global__ void __launch_bounds__(kLossThreads) pd_loss_kernel(const float* __re
   }
 }
 
+// Pairwise debiasing for short lists (L <= 16): one lane per (list, rank k), a list = 16 consecutive lanes, so
+// the L partners of a document are shuffles within the group and the L x L pair terms of a list cost L steps
+// instead of L^2 (the one-thread-per-list kernel above ran the whole headline batch on ONE CU: 85 us).  Lane (b, k)
+// forms the pair losses l_kj and the gradient wrt o_k in the same walk over j.  Batch sums: the four lists of a
+// wave meet by lane exchange, the waves in LDS, the blocks in the workspace (fixed order, last block reduces).
+__global__ void __launch_bounds__(kLossThreads) pd_loss_small_kernel(const float* __restrict__ scores,
+                                                                     const float* __restrict__ clicks, int B, int L,
+                                                                     const float* __restrict__ t_plus,
+                                                                     const float* __restrict__ t_minus,
+                                                                     float* __restrict__ d_scores,
+                                                                     float* __restrict__ stats, float* ws) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  __shared__ float s_tp[16], s_tm[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & 15, li = tid >> 4, gbase = lane & 48;
+  const bool in_list = r < L;
+  const float tp_k = in_list ? t_plus[r] : 1.f, tm_k = in_list ? t_minus[r] : 1.f;
+  if (tid < 16) {
+    s_tp[tid] = tp_k;
+    s_tm[tid] = tm_k;
+  }
+  float pl[16];  // l_kj summed over this lane's lists, j = 0..15
+#pragma unroll
+  for (int j = 0; j < 16; ++j) pl[j] = 0.f;
+  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
+    const long long b = b0 + li;
+    const bool live = in_list && b < B;
+    const long long e = (long long)r * B + (b < B ? b : 0);
+    const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < L) {  // uniform
+        const float oj = __shfl(o, gbase + j, 64), cj = __shfl(c, gbase + j, 64);
+        const float tpj = __shfl(tp_k, gbase + j, 64), tmj = __shfl(tm_k, gbase + j, 64);
+        const float m1 = fminf(1.f, fmaxf(c - cj, 0.f));  // min(1, relu(c_k - c_j))  (:147-150)
+        const float m2 = fminf(1.f, fmaxf(cj - c, 0.f));
+        if (live && j != r && (m1 > 0.f || m2 > 0.f)) {
+          // one exponential serves both: softplus(d) = max(d, 0) + log1p(e), sigmoid(d) = (d >= 0 ? 1 : e) / (1 + e)
+          const float diff = oj - o;
+          const float ex = expf(-fabsf(diff));
+          const float inv = 1.f / (1.f + ex);
+          const float sg = diff >= 0.f ? inv : ex * inv;   // d softplus(o_j - o_k) / d o_j
+          pl[j] += m1 * (fmaxf(diff, 0.f) + log1pf(ex));   // softplus(o_j - o_k)  (:151-155)
+          acc += m2 / (tpj * tm_k) * (1.f - sg) - m1 / (tp_k * tmj) * sg;  // pair (j, k): sig(o_k - o_j) ; pair (k, j)
+        }
+      }
+    }
+    if (live) d_scores[e] = acc;
+  }
+  // the four lists of the wave (same rank k: lanes k, k+16, k+32, k+48), then the waves
+  float* mine = s_part + wid * kMaxStat;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float o1, o2;
+    float v = xor16_partner(pl[j], &o1);
+    v += o1;
+    v = xor32_partner(v, &o2) + o2;
+    if (lane < L && j < L) mine[lane * L + j] = v;
+  }
+  if (lane == 0) mine[L * L] = 0.f;
+  BlockStats bs{s_part};
+  bs.combine(s_acc, L * L + 1, 1 << 30);
+  if (finish_stats(s_acc, L * L + 1, 1 << 30, ws, stats)) {  // block-uniform
+    // loss = sum_ij l_ij / t+_i / t-_j  (:158-159), pre-update ratios: one term per thread, then a block sum
+    __shared__ float red[4];
+    float term[1] = {0.f};
+    if (tid < L * L && tid / L != tid % L) term[0] = s_acc[tid] / s_tp[tid / L] / s_tm[tid % L];
+    block_sum<1>(term, red);
+    if (tid == 0) stats[L * L] = term[0];
+  }
+}
+
 // t+_i <- (1-s) t+_i + s (A_i/A_0)^(1/(p+1)), A_i = sum_j l_ij/t-_j ; t-_j likewise (:162-171)
 __global__ void pd_update_kernel(float* t_plus, float* t_minus, int L, float* stats, float s, float reg_p,
                                  float* old_out) {
   __shared__ float A[kPdMaxL], Am[kPdMaxL], tp[kPdMaxL], tm[kPdMaxL];
+  __shared__ float s_l[kPdMaxL * kPdMaxL];  // the pair matrix: one round of independent loads instead of L^2 serial ones
   const int k = threadIdx.x;
+  for (int i = k; i < L * L; i += blockDim.x) s_l[i] = stats[i];
   if (k < L) {
     tp[k] = t_plus[k];
     tm[k] = t_minus[k];
@@ -549,12 +764,14 @@ __global__ void pd_update_kernel(float* t_plus, float* t_minus, int L, float* st
     }
   }
   __syncthreads();
+  float row = 0.f;
   if (k < L) {
     float a = 0.f, am = 0.f;
     for (int j = 0; j < L; ++j) {
       if (j == k) continue;
-      a += stats[k * L + j] / tm[j];   // t_plus_loss_list[k]
-      am += stats[j * L + k] / tp[j];  // t_minus_loss_list[k]
+      a += s_l[k * L + j] / tm[j];   // t_plus_loss_list[k]
+      am += s_l[j * L + k] / tp[j];  // t_minus_loss_list[k]
+      row += s_l[k * L + j] / tp[k] / tm[j];
     }
     A[k] = a;
     Am[k] = am;
@@ -565,12 +782,11 @@ __global__ void pd_update_kernel(float* t_plus, float* t_minus, int L, float* st
     t_plus[k] = (1.f - s) * tp[k] + s * powf(A[k] / A[0], e);
     t_minus[k] = (1.f - s) * tm[k] + s * powf(Am[k] / Am[0], e);
   }
-  if (k == 0) {  // loss with the all-reduced pair matrix (data-parallel runs recompute it here)
-    float loss = 0.f;
-    for (int i = 0; i < L; ++i)
-      for (int j = 0; j < L; ++j)
-        if (i != j) loss += stats[i * L + j] / tp[i] / tm[j];
-    stats[L * L] = loss;
+  {  // loss with the all-reduced pair matrix (data-parallel runs recompute it here): row sums, then one wave sum
+    const float loss = wave_sum(row);
+    if (k == 0) {
+      stats[L * L] = loss;
+    }
   }
 }
 
@@ -601,6 +817,16 @@ extern "C" int ultr_loss_ipw_fwdbwd(const float* scores, const float* clicks, co
   ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
                "ultr_loss_ipw_fwdbwd: loss_func=%d (pairwise_loss raises NameError in the reference and is not "
                "supported)", loss_func);
+  if (L <= 16) {
+    long long blocks = cdiv(B, 16);
+    if (blocks > 1024) blocks = 1024;  // partial rows stay bounded; a block then walks several groups of 16 lists
+    {
+      ultr::ProfScope prof_("ipw_loss_kernel", as_stream(stream));
+      hipLaunchKernelGGL(ipw_loss_small_kernel, dim3((unsigned)blocks), dim3(kLossThreads), 0, as_stream(stream), scores,
+                       clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
+    }
+    return check_launch("ipw_loss_small_kernel");
+  }
   {
     ultr::ProfScope prof_("ipw_loss_kernel", as_stream(stream));
     hipLaunchKernelGGL(ipw_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
@@ -652,6 +878,17 @@ extern "C" int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, in
   int rc = loss_args_ok("ultr_loss_rem_fwdbwd", scores, clicks, B, L, ws);
   if (rc) return rc;
   ULTR_REQUIRE(propensity && d_scores && stats, ULTR_EINVAL, "ultr_loss_rem_fwdbwd: null pointer");
+  if (L <= 16) {
+    long long blocks = cdiv(B, 16);
+    if (blocks > 1024) blocks = 1024;  // partial rows stay bounded; a block then walks several groups of 16 lists
+    {
+      ultr::ProfScope prof_("rem_loss_kernel", as_stream(stream));
+      hipLaunchKernelGGL(rem_loss_small_kernel, dim3((unsigned)blocks), dim3(kLossThreads), 0, as_stream(stream), scores,
+                       clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base, d_scores,
+                       ranker_labels, list_weights, stats, d_bias, ws);
+    }
+    return check_launch("rem_loss_small_kernel");
+  }
   {
     ultr::ProfScope prof_("rem_loss_kernel", as_stream(stream));
     hipLaunchKernelGGL(rem_loss_kernel, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0, as_stream(stream),
@@ -677,6 +914,16 @@ extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int
   if (rc) return rc;
   ULTR_REQUIRE(t_plus && t_minus && d_scores && stats, ULTR_EINVAL, "ultr_loss_pd_fwdbwd: null pointer");
   ULTR_REQUIRE(L <= kPdMaxL, ULTR_ELIMIT, "ultr_loss_pd_fwdbwd: L=%d > %d", L, kPdMaxL);
+  if (L <= 16) {
+    long long blocks = cdiv(B, 16);
+    if (blocks > 1024) blocks = 1024;  // partial rows stay bounded; a block then walks several groups of 16 lists
+    {
+      ultr::ProfScope prof_("pd_loss_kernel", as_stream(stream));
+      hipLaunchKernelGGL(pd_loss_small_kernel, dim3((unsigned)blocks), dim3(kLossThreads), 0, as_stream(stream), scores,
+                       clicks, B, L, t_plus, t_minus, d_scores, stats, ws);
+    }
+    return check_launch("pd_loss_small_kernel");
+  }
   const size_t smem = sizeof(float) * ((size_t)2 * L * kLossThreads + (size_t)L * L + 1 + (size_t)4 * L * L);
   if (smem > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pd_loss_kernel),
