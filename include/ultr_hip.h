@@ -197,6 +197,20 @@ int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, int B, int L,
                          int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
                          float* prop_grads, float* list_weights, float* stats, float* ws, void* stream);
 
+/* ultr_loss_dla_fwdbwd with the launch deferred: same arguments and results, but for L <= 16 nothing is launched
+ * here -- the request is parked and the NEXT ultr_dnn_backward / ultr_dnn_backward_sumsq call of this host thread
+ * carries it inside its FIRST launch, provided that call's d_scores is this request's d_scores and its M equals
+ * B * L: the loss kernel's workgroups ride along (statistics, tower gradient, list weights, d_scores), and the
+ * backward workgroups evaluate the d_score of their own rows from scores / clicks / prop_params instead of reading
+ * it, so the step's chain of dependent launches is one shorter (dla.py:119-180 is a sub-graph of the same
+ * session.run as tf.gradients, :237-239).  All pointers must stay valid until that call.  Otherwise (longer lists,
+ * another d_scores buffer, no hidden layer wider than 1024) the request is launched on its own, first.
+ * ultr_loss_flush launches a parked request on its own (no-op when there is none). */
+int ultr_loss_dla_deferred(const float* scores, const float* clicks, int B, int L, const float* prop_params,
+                           int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
+                           float* prop_grads, float* list_weights, float* stats, float* ws, void* stream);
+int ultr_loss_flush(void* stream);
+
 /* Regression-EM (regression_EM.py:116-176).  propensity [L] is the EM state (read, pre-update
  * value used for loss and gradient, q16).  uniforms [L][B] fp32 or NULL (Philox(seed, step)).
  *   d_scores un-normalised (divide by B_global); d_bias[0] (may be NULL) = sum of d_scores, the

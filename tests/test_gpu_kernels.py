@@ -564,6 +564,50 @@ def test_dnn_forward_backward(L, F, hidden, act, norm, B, Ls):
     assert abs(float(sumsq.double().sum()) - want_sq) <= 1e-5 * max(want_sq, 1e-30)
 
 
+@pytest.mark.parametrize('F,hidden,B,Ls,loss_func,prob,maxw', [
+    (136, [512, 256, 128], 256, 10, 0, 0, -1.0),   # BASELINE config 2
+    (136, [512, 256, 128], 100, 9, 1, 0, -1.0),    # ragged M, sigmoid loss
+    (46, [64, 32], 50, 16, 0, 1, 3.0),             # longest short list, clipped weights
+    (136, [], 40, 10, 0, 0, -1.0),                 # no hidden layer
+    (64, [300], 4100, 3, 0, 0, -1.0),              # more lists than one grid of loss workgroups covers at once
+])
+def test_dla_loss_rides_with_backward(L, F, hidden, B, Ls, loss_func, prob, maxw):
+    """ultr_loss_dla_deferred: the loss carried by the backward pass's first launch (which then evaluates the d_scores of
+    its rows itself) against a loss launch of its own followed by the same backward pass -- same statistics, d_scores,
+    tower gradient, list weights and parameter gradient, bit for bit; and the fall-backs (flush, another d_scores buffer)."""
+    model, ps, data, table, stats, n_rows, docids, d_lb, rng = _dnn_case(L, F, hidden, 'elu', 'layer', B, Ls, seed=F + B)
+    scores = model.forward_lists(table, stats, n_rows, d_lb)
+    clicks = dev(_scores_clicks(rng, B, Ls)[1].T, torch.float32)
+    pp = dev(np.concatenate([rng.uniform(-0.7, 0.7, size=Ls), rng.uniform(-0.5, 0.5, size=1)]), torch.float32)
+    lib = L.lib()
+
+    def run(mode):
+        d = torch.full((Ls, B), 3.0, dtype=torch.float32, device='cuda')
+        pg = torch.zeros(Ls + 1, dtype=torch.float32, device='cuda')
+        lw = torch.zeros(B, dtype=torch.float32, device='cuda')
+        st = torch.zeros(4 + 3 * Ls, dtype=torch.float32, device='cuda')
+        ws = _loss_ws(L, B, Ls)
+        grads = torch.full((model.n_total,), 7.0, dtype=torch.float32, device='cuda')
+        fn = lib.ultr_loss_dla_fwdbwd if mode == 'plain' else lib.ultr_loss_dla_deferred
+        for _ in range(2):  # twice: arrival counters must be left clean
+            L.check(fn(L.ptr(scores), L.ptr(clicks), B, Ls, L.ptr(pp), loss_func, prob, maxw, L.ptr(d), L.ptr(pg),
+                       L.ptr(lw), L.ptr(st), L.ptr(ws), stream(L)), 'dla')
+            if mode == 'flush':
+                L.check(lib.ultr_loss_flush(stream(L)), 'flush')
+            if mode == 'other_buffer':  # the pass reads another d_scores buffer: the parked loss runs first, on its own
+                model.backward(torch.zeros_like(d), torch.empty_like(grads))
+            model.backward(d, grads)
+        L.check(lib.ultr_loss_flush(stream(L)), 'flush')  # nothing left parked
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (d, pg, lw, st, grads)]
+    want = run('plain')
+    assert np.abs(want[0] - 3.0).min() > 0 and np.abs(want[4][:model.desc.n_params]).max() > 0
+    for mode in ('ride', 'flush', 'other_buffer'):
+        got = run(mode)
+        for a, b, name in zip(got, want, ('d_scores', 'prop_grads', 'list_weights', 'stats', 'grads')):
+            assert np.array_equal(a, b), (mode, name, np.abs(a - b).max())
+
+
 def test_dnn_build_reference_api(L):
     from ultra_amd.ranking_model import DNN
     rng = np.random.RandomState(0)
@@ -584,7 +628,7 @@ def test_dnn_build_reference_api(L):
 
 
 @pytest.mark.parametrize('env', [{'ULTR_FWD_CHAIN': '0'}, {'ULTR_BWD_CHAIN': '1'}, {'ULTR_BWD_PAIR': '3'},
-                                 {'ULTR_METRICS_RIDE': '0'}, {'ULTR_FUSED_TAIL': '0'}])
+                                 {'ULTR_METRICS_RIDE': '0'}, {'ULTR_FUSED_TAIL': '0'}, {'ULTR_LOSS_RIDE': '0'}])
 def test_alternate_kernel_paths_in_a_fresh_process(env):
     """The library picks its launch plan from the shapes; the plans that the default shapes no longer reach (per-layer
     forward kernels, the backward chain, paired wgrad+dgrad for every layer, a metric launch of its own, norm pass and result copy as launches of their own) are switched

@@ -20,6 +20,7 @@
 //    LayerNorm backward and the activation derivative (from the stored activation output).
 #include "metrics_body.hpp"
 #include "feed_body.hpp"
+#include "loss_body.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -964,6 +965,11 @@ struct BwdOutArgs {
   int rows_per_block;
   float* partials;         // [gridDim.x][3K+4]: dW[K], dgamma[K], dbeta[K], db
   float* zero; long long zero_n4;  // the flat gradient buffer, cleared here (float4 units) instead of by a memset node
+  // ultr_loss_dla_deferred: the launch carries the DLA loss.  Its first dla_pad workgroups (dla_blocks of them live)
+  // are the loss kernel's own -- statistics, tower gradient, list weights, d_scores for whoever reads them later --
+  // and the backward workgroups evaluate the d_score of each of their rows themselves (dla_lane) instead of
+  // waiting for a loss launch to have written it: one launch less in the chain of dependent kernels.
+  DlaArgs dla; int dla_blocks, dla_pad;
 };
 
 // generic fallback for very wide inputs (no hidden layer and more than 1024 features): LDS accumulators
@@ -1038,13 +1044,23 @@ __global__ void __launch_bounds__(kThreads) bwd_out_wide_kernel(BwdOutArgs p) {
 // One wave per row, four rows in flight per wave (all their loads are issued before the first use); lane l
 // owns columns k = l + 64 q and keeps the parameter-gradient sums of its columns in registers across the
 // wave's rows.  The four waves of a workgroup meet in LDS and write one partial row; finalize adds the rows.
-template <int KQ>
+template <int KQ, bool DLA>
 __global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
   extern __shared__ float smem[];  // [4 waves][3K+1]
+  if (DLA && (int)blockIdx.x < p.dla_pad) {
+    __shared__ float s_acc[kMaxStat];
+    __shared__ float s_part[4 * kMaxStat];
+    __shared__ float s_tower[4 * 16];
+    if ((int)blockIdx.x < p.dla_blocks) dla_loss_small_body(p.dla, blockIdx.x, p.dla_blocks, s_acc, s_part, s_tower);
+    return;
+  }
+  const unsigned int bid = blockIdx.x - (DLA ? p.dla_pad : 0), nbid = gridDim.x - (DLA ? p.dla_pad : 0);
   const int K = p.f.K;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < p.zero_n4; i += (long long)gridDim.x * kThreads)
+  for (long long i = (long long)bid * kThreads + threadIdx.x; i < p.zero_n4; i += (long long)nbid * kThreads)
     reinterpret_cast<float4*>(p.zero)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float tower_pw = 0.f;  // DLA: inverse propensity weight of rank lane & 15
+  if (DLA) tower_pw = dla_tower(p.dla.prop_params, p.dla.L, lane & 15, p.dla.prob_kind, p.dla.max_pw).pw;
   float wv[KQ], gv[KQ], bv[KQ], aW[KQ], aG[KQ], aB[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
@@ -1056,19 +1072,29 @@ __global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
     aW[q] = aG[q] = aB[q] = 0.f;
   }
   float db = 0.f;
-  const long long m_begin = (long long)blockIdx.x * p.rows_per_block;
+  const long long m_begin = (long long)bid * p.rows_per_block;
   long long m_end = m_begin + p.rows_per_block;
   if (m_end > p.f.M) m_end = p.f.M;
   const float inv_k = 1.f / (float)K;
   for (long long mb = m_begin + w; mb < m_end; mb += 16) {  // rows mb, mb + 4, mb + 8, mb + 12
     float x[4][KQ], go[4], mean[4], rstd[4];
     bool live[4];
+    float go_group = 0.f;
+    if (DLA) {  // lanes 16 u .. 16 u + 15 evaluate the list of row mb + 4 u, one rank each, and keep that row's d_score
+      const long long mg = min(mb + 4 * (lane >> 4), m_end - 1);
+      const int r = lane & 15, lg = (int)(mg / p.dla.B);
+      const long long e = (long long)r * p.dla.B + (mg - (long long)lg * p.dla.B);
+      const bool lv = r < p.dla.L;
+      const float o = lv ? p.dla.scores[e] : 0.f, c = lv ? p.dla.clicks[e] : 0.f;
+      const DlaLane v = dla_lane(o, c, tower_pw, lv, p.dla.loss_func);
+      go_group = group_sum<16>(r == lg ? v.ds : 0.f);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long m = mb + 4 * u;
       live[u] = m < m_end;
       const long long mc = live[u] ? m : m_end - 1;
-      go[u] = p.d_scores[mc];
+      go[u] = DLA ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(go_group), 16 * u)) : p.d_scores[mc];
       const float* src;
       mean[u] = 0.f; rstd[u] = 1.f;
       bool pad = false;
@@ -1155,7 +1181,7 @@ __global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
   }
   if (lane == 0) acc[3 * K] = db;
   __syncthreads();
-  float* out = p.partials + (long long)blockIdx.x * (3 * K + 4);
+  float* out = p.partials + (long long)bid * (3 * K + 4);
   for (int i = threadIdx.x; i < 3 * K + 1; i += blockDim.x) {
     const int stride = 3 * K + 1;
     out[i] = smem[i] + smem[stride + i] + smem[2 * stride + i] + smem[3 * stride + i];
@@ -2085,12 +2111,29 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
     const size_t smem = sizeof(float) * 4 * (3 * (size_t)L.K[H] + 1);
     ULTR_REQUIRE(smem <= 64 * 1024, ULTR_ELIMIT, "ultr_dnn_backward: output layer input width %d too large", L.K[H]);
     ULTR_REQUIRE(H == 0 || L.K[H] <= 1024, ULTR_ELIMIT, "ultr_dnn_backward: hidden width %d beyond %d", L.K[H], 1024);
+    // A parked DLA loss (ultr_loss_dla_deferred) rides with this launch when it describes this very batch
+    bool fuse_dla = false;
+    if (g_pending_dla.on) {
+      const DlaArgs& pa = g_pending_dla.a;
+      fuse_dla = L.K[H] <= 1024 && pa.d_scores == d_scores && pa.L <= 16 && (long long)pa.B * pa.L == M;
+      g_pending_dla.on = false;
+      if (fuse_dla) {
+        b.dla = pa; b.dla_blocks = (int)g_pending_dla.nblocks; b.dla_pad = (b.dla_blocks + 7) & ~7;
+      } else {
+        rc = launch_dla_now(pa, g_pending_dla.nblocks, st);
+        if (rc) return rc;
+      }
+    }
     {
-      ultr::ProfScope prof_("bwd_out_kernel", st);
-      const dim3 grid((unsigned)L.out_blocks), block(kThreads);
-      if (L.K[H] <= 128) hipLaunchKernelGGL(bwd_out_kernel<2>, grid, block, smem, st, b);
-      else if (L.K[H] <= 256) hipLaunchKernelGGL(bwd_out_kernel<4>, grid, block, smem, st, b);
-      else if (L.K[H] <= 1024) hipLaunchKernelGGL(bwd_out_kernel<16>, grid, block, smem, st, b);
+      ultr::ProfScope prof_(fuse_dla ? "bwd_out_kernel+dla_loss" : "bwd_out_kernel", st);
+      const dim3 grid((unsigned)(L.out_blocks + b.dla_pad)), block(kThreads);
+      if (fuse_dla) {
+        if (L.K[H] <= 128) hipLaunchKernelGGL((bwd_out_kernel<2, true>), grid, block, smem, st, b);
+        else if (L.K[H] <= 256) hipLaunchKernelGGL((bwd_out_kernel<4, true>), grid, block, smem, st, b);
+        else hipLaunchKernelGGL((bwd_out_kernel<16, true>), grid, block, smem, st, b);
+      } else if (L.K[H] <= 128) hipLaunchKernelGGL((bwd_out_kernel<2, false>), grid, block, smem, st, b);
+      else if (L.K[H] <= 256) hipLaunchKernelGGL((bwd_out_kernel<4, false>), grid, block, smem, st, b);
+      else if (L.K[H] <= 1024) hipLaunchKernelGGL((bwd_out_kernel<16, false>), grid, block, smem, st, b);
       else hipLaunchKernelGGL(bwd_out_wide_kernel, grid, block, smem, st, b);
     }
     rc = check_launch("bwd_out_kernel");

@@ -7,67 +7,10 @@
 // 64 lanes of a wave read 64 consecutive floats of one rank: every access is coalesced.
 // Batch sums: per-wave shuffles -> per-block LDS (fixed order) -> per-block partial row in the
 // workspace -> the last block to arrive sums the rows in block order (deterministic).
-#include "common.hpp"
+#include "loss_body.hpp"
 
 namespace ultr {
 
-constexpr int kLossThreads = 256;
-constexpr int kMaxStat = 4 + 4 * ULTR_MAX_LIST;  // widest partial row (DLA / REM)
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-// tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|))
-__device__ __forceinline__ float sig_ce(float z, float x) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
-__device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x); }
-__device__ __forceinline__ float clip_w(float w, float maxw) { return maxw > 0.f ? fminf(fmaxf(w, 0.f), maxw) : w; }
-
-// Per-block accumulation of batch sums (or maxima), fixed order and barrier-free until combine():
-// add() reduces across the wave with shuffles and parks the result in the wave's LDS row.
-struct BlockStats {
-  float* s_part;  // [4 waves][kMaxStat]
-  __device__ __forceinline__ void add(int slot, float v, bool is_max = false) {
-    v = is_max ? wave_max(v) : wave_sum(v);
-    if ((threadIdx.x & 63) == 0) s_part[(threadIdx.x >> 6) * kMaxStat + slot] = v;
-  }
-  __device__ __forceinline__ void combine(float* s_acc, int ns, int max_from) {
-    __syncthreads();
-    const int nw = blockDim.x >> 6;
-    for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-      float r = s_part[s];
-      for (int w = 1; w < nw; ++w) r = (s >= max_from) ? fmaxf(r, s_part[w * kMaxStat + s]) : r + s_part[w * kMaxStat + s];
-      s_acc[s] = r;
-    }
-  }
-};
-
-// Publish this block's row, and in the last block reduce all rows into out[0..ns).  Slots >=
-// max_from are reduced with max instead of +.  Returns true in the (single) last block, with the
-// totals also left in s_acc.
-__device__ __forceinline__ bool finish_stats(float* s_acc, int ns, int max_from, float* ws, float* out) {
-  unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
-  float* rows = ws + 8;
-  __syncthreads();
-  for (int s = threadIdx.x; s < ns; s += blockDim.x) rows[(long long)blockIdx.x * ns + s] = s_acc[s];
-  const bool last = last_block_arrive(counter, gridDim.x);
-  if (last) {
-    __shared__ float s_tmp[kLossThreads];
-    if (ns <= (int)blockDim.x) {
-      reduce_rows(rows, (int)gridDim.x, ns, max_from, s_tmp, s_acc);
-    } else {  // rows wider than the block (L = 64 with the widest statistics): plain column walk
-      for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-        float r = rows[s];
-        for (unsigned int b = 1; b < gridDim.x; ++b) {
-          const float v = rows[(long long)b * ns + s];
-          r = (s >= max_from) ? fmaxf(r, v) : r + v;
-        }
-        s_acc[s] = r;
-      }
-      __syncthreads();
-    }
-    for (int s = threadIdx.x; s < ns; s += blockDim.x) out[s] = s_acc[s];
-    __syncthreads();
-  }
-  return last;
-}
 
 // ------------------------------------------------------------------------------------------
 // IPW: softmax_loss / sigmoid_loss_on_list with per-element weights
@@ -325,122 +268,13 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
   }
 }
 
-// DLA for short lists (L <= 16): one lane per (list, rank), a list = 16 consecutive lanes, so the
-// per-list softmaxes are DPP group reductions and each lane evaluates ONE exp instead of L.  At batch
-// 256 this spreads the step's loss over 16 CUs instead of 4 waves on one CU.
-__global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(
-    const float* __restrict__ scores, const float* __restrict__ clicks, int B, int L,
-    const float* __restrict__ prop_params, int loss_func, int prob_kind, float max_pw,
-    float* __restrict__ d_scores, float* __restrict__ prop_grads, float* __restrict__ list_weights,
-    float* __restrict__ stats, float* ws) {
+// DLA for short lists (L <= 16): body in loss_body.hpp, shared with the backward pass's first launch, which can
+// carry it (ultr_loss_dla_deferred).
+__global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(DlaArgs a) {
   __shared__ float s_acc[kMaxStat];
   __shared__ float s_part[4 * kMaxStat];
-  __shared__ float s_tower[4][16];  // pre, logit, logp, pw for the last block's chain rule
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = tid & 15, li = tid >> 4;
-  const bool in_list = r < L;
-  // propensity tower (batch independent; every 16-lane group evaluates it): logit_r = ELU(W[r] + b)
-  const float pre = in_list ? prop_params[r] + prop_params[L] : 0.f;
-  const float logit = eluf_(pre);
-  const float tm = group_max<16>(in_list ? logit : -INFINITY);
-  const float te = in_list ? expf(logit - tm) : 0.f;
-  const float tse = group_sum<16>(te);
-  const float logp = logit - tm - logf(tse);
-  const float tmean = group_sum<16>(in_list ? logit : 0.f) / (float)L;
-  const float tprob = prob_kind == ULTR_PROB_SOFTMAX ? te / tse : sigmoidf_(logit - tmean);
-  const float tprob0 = group_sum<16>(r == 0 ? tprob : 0.f);
-  const float pw = in_list ? clip_w(tprob0 / tprob, max_pw) : 0.f;  // dla.py:352-364
-  if (tid < 16) {
-    s_tower[0][tid] = pre;
-    s_tower[1][tid] = logit;
-    s_tower[2][tid] = logp;
-    s_tower[3][tid] = pw;
-  }
-  // The grid is capped (ultr_loss_workspace_floats): beyond 16 * gridDim.x lists a block walks several groups
-  // of 16 lists and keeps its per-lane sums in registers, so the number of partial rows stays bounded.
-  float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f, col = 0.f, rw_sum = 0.f;
-  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
-    const long long b = b0 + li;
-    const bool live = in_list && b < B;
-    const long long e = (long long)r * B + (b < B ? b : 0);
-    const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f;
-    // the list's own softmax / relevance weights
-    const float m = group_max<16>(live ? o : -INFINITY);
-    const float ex = live ? expf(o - m) : 0.f;
-    const float se = group_sum<16>(ex);
-    const float mean = group_sum<16>(live ? o : 0.f) / (float)L;
-    const float pl = prob_kind == ULTR_PROB_SOFTMAX ? ex / se : sigmoidf_(o - mean);
-    const float p0 = group_sum<16>(r == 0 ? pl : 0.f);
-    const float rw = live ? clip_w(p0 / pl, max_pw) : 0.f;  // relevance weights (dla.py:159-160)
-    const float wl = live ? (c + 0.0000001f) * pw : 0.f;
-    const float S = group_sum<16>(wl);
-    const float lse = m + logf(se);
-    const float cl = fminf(fmaxf(c, 0.f), 1.f);
-    const float lw = group_sum<16>(live ? pw * cl : 0.f);
-    rw_sum += rw;
-    if (live) {
-      if (loss_func == ULTR_LOSS_SOFTMAX) {
-        rank_num += -wl * (o - lse);
-        d_scores[e] = expf(o - lse) * S - wl;
-        const float wle = (c + 0.0000001f) * rw;
-        exam_num += -wle * logp;
-        exam_den += wle;
-        col += wle;  // d exam/d logit_l = softmax(logit)_l * sum_b S'_b - sum_b wle
-        rank_den += r == 0 ? S : 0.f;
-      } else {
-        const float z = fminf(c, 1.f);
-        rank_num += sig_ce(z, o) * pw;
-        d_scores[e] = (sigmoidf_(o) - z) * pw;
-        exam_num += sig_ce(z, logit) * rw;
-        col += (sigmoidf_(logit) - z) * rw;  // d exam/d logit_l directly
-        rank_den += r == 0 ? 1.f : 0.f;
-        exam_den += r == 0 ? 1.f : 0.f;
-      }
-      if (r == 0 && list_weights) list_weights[b] = lw / (float)L;
-    }
-  }
-  const float rw = rw_sum;
-  // batch sums: scalars over the whole wave; per-rank columns over the wave's 4 lists (xor 16, xor 32)
-  rank_num = wave_sum(rank_num);
-  rank_den = wave_sum(rank_den);
-  exam_num = wave_sum(exam_num);
-  exam_den = wave_sum(exam_den);
-  float o1, o2;
-  float rws = xor16_partner(rw, &o1);
-  rws += o1;
-  rws = xor32_partner(rws, &o2) + o2;
-  float cols = xor16_partner(col, &o1);
-  cols += o1;
-  cols = xor32_partner(cols, &o2) + o2;
-  float* mine = s_part + wid * kMaxStat;
-  if (lane == 0) {
-    mine[0] = rank_num;
-    mine[1] = rank_den;
-    mine[2] = exam_num;
-    mine[3] = exam_den;
-  }
-  if (lane < L) {
-    mine[4 + lane] = 0.f;  // pw_l is batch independent: written once by the last block
-    mine[4 + L + lane] = rws;
-    mine[4 + 2 * L + lane] = cols;
-  }
-  BlockStats bs{s_part};
-  bs.combine(s_acc, 4 + 3 * L, 1 << 30);
-  if (finish_stats(s_acc, 4 + 3 * L, 1 << 30, ws, stats)) {
-    if (tid < L) stats[4 + tid] = s_tower[3][tid];
-    if (tid < 64) {  // chain through the tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l
-      float dpre = 0.f;  // one rank per lane, the bias gradient is their wave sum
-      if (tid < L) {
-        const int l = tid;
-        const float dlogit = loss_func == ULTR_LOSS_SOFTMAX ? expf(s_tower[2][l]) * s_acc[3] - s_acc[4 + 2 * L + l]
-                                                            : s_acc[4 + 2 * L + l];
-        dpre = dlogit * (s_tower[0][l] > 0.f ? 1.f : s_tower[1][l] + 1.f);
-        prop_grads[l] = dpre;
-      }
-      const float db = wave_sum(dpre);
-      if (tid == 0) prop_grads[L] = db;
-    }
-  }
+  __shared__ float s_tower[4 * 16];  // pre, logit, logp, pw for the last block's chain rule
+  dla_loss_small_body(a, blockIdx.x, gridDim.x, s_acc, s_part, s_tower);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -846,28 +680,76 @@ extern "C" int ultr_ipw_weights(const float* clicks, int B, int L, const float* 
   return check_launch("ipw_weights_kernel");
 }
 
+namespace ultr {
+thread_local PendingDla g_pending_dla = {};
+
+static inline unsigned dla_small_blocks(int B) { return (unsigned)(cdiv(B, 16) < 1024 ? cdiv(B, 16) : 1024); }
+
+int launch_dla_now(const DlaArgs& a, unsigned nblocks, hipStream_t st) {
+  {
+    ultr::ProfScope prof_("dla_loss_kernel", st);
+    hipLaunchKernelGGL(dla_loss_small_kernel, dim3(nblocks), dim3(kLossThreads), 0, st, a);
+  }
+  return check_launch("dla_loss_kernel");
+}
+}  // namespace ultr
+
+static int dla_args(const char* who, DlaArgs* a, const float* scores, const float* clicks, int B, int L,
+                    const float* prop_params, int loss_func, int logits_to_prob, float max_propensity_weight,
+                    float* d_scores, float* prop_grads, float* list_weights, float* stats, float* ws) {
+  int rc = loss_args_ok(who, scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(prop_params && d_scores && prop_grads && stats, ULTR_EINVAL, "%s: null pointer", who);
+  ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
+               "%s: loss_func=%d not supported", who, loss_func);
+  ULTR_REQUIRE(logits_to_prob == ULTR_PROB_SOFTMAX || logits_to_prob == ULTR_PROB_SIGMOID, ULTR_EINVAL,
+               "%s: logits_to_prob=%d", who, logits_to_prob);
+  *a = DlaArgs{scores, clicks, B, L, prop_params, loss_func, logits_to_prob, max_propensity_weight,
+               d_scores, prop_grads, list_weights, stats, ws};
+  return ULTR_OK;
+}
+
+extern "C" int ultr_loss_flush(void* stream) {
+  if (!g_pending_dla.on) return ULTR_OK;
+  g_pending_dla.on = false;
+  return launch_dla_now(g_pending_dla.a, g_pending_dla.nblocks, as_stream(stream));
+}
+
 extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* prop_params,
                                     int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
                                     float* prop_grads, float* list_weights, float* stats, float* ws, void* stream) {
-  int rc = loss_args_ok("ultr_loss_dla_fwdbwd", scores, clicks, B, L, ws);
+  DlaArgs a;
+  int rc = dla_args("ultr_loss_dla_fwdbwd", &a, scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                    max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
   if (rc) return rc;
-  ULTR_REQUIRE(prop_params && d_scores && prop_grads && stats, ULTR_EINVAL, "ultr_loss_dla_fwdbwd: null pointer");
-  ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
-               "ultr_loss_dla_fwdbwd: loss_func=%d not supported", loss_func);
-  ULTR_REQUIRE(logits_to_prob == ULTR_PROB_SOFTMAX || logits_to_prob == ULTR_PROB_SIGMOID, ULTR_EINVAL,
-               "ultr_loss_dla_fwdbwd: logits_to_prob=%d", logits_to_prob);
+  rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
+  if (rc) return rc;
+  if (L <= 16) return launch_dla_now(a, dla_small_blocks(B), as_stream(stream));
   {
     ultr::ProfScope prof_("dla_loss_kernel", as_stream(stream));
-    if (L <= 16)
-      hipLaunchKernelGGL(dla_loss_small_kernel, dim3((unsigned)(cdiv(B, 16) < 1024 ? cdiv(B, 16) : 1024)), dim3(kLossThreads), 0,
-                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
-                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
-    else
-      hipLaunchKernelGGL(dla_loss_kernel<64>, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0,
-                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
-                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
+    hipLaunchKernelGGL(dla_loss_kernel<64>, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0,
+                       as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                       max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
   }
   return check_launch("dla_loss_kernel");
+}
+
+extern "C" int ultr_loss_dla_deferred(const float* scores, const float* clicks, int B, int L, const float* prop_params,
+                                      int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
+                                      float* prop_grads, float* list_weights, float* stats, float* ws, void* stream) {
+  if (L > 16)  // only the short-list kernel has a body another launch can carry
+    return ultr_loss_dla_fwdbwd(scores, clicks, B, L, prop_params, loss_func, logits_to_prob, max_propensity_weight,
+                                d_scores, prop_grads, list_weights, stats, ws, stream);
+  DlaArgs a;
+  int rc = dla_args("ultr_loss_dla_deferred", &a, scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                    max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
+  if (rc) return rc;
+  rc = ultr_loss_flush(stream);
+  if (rc) return rc;
+  g_pending_dla.on = true;
+  g_pending_dla.a = a;
+  g_pending_dla.nblocks = dla_small_blocks(B);
+  return ULTR_OK;
 }
 
 extern "C" int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* propensity,

@@ -258,6 +258,9 @@ class BaseAlgorithm(ABC):
                                   tb['list_weights'] if weighted else None, tb['metrics'], tb['met_ws'], u,
                                   deferred=deferred)
 
+    # ULTR_LOSS_RIDE=0: the loss kernel gets a launch of its own instead of riding with the backward pass's first one
+    ride_loss = os.environ.get('ULTR_LOSS_RIDE', '1') != '0'
+
     # ULTR_FUSED_TAIL=0: norm pass and result copy as launches of their own
     fused_tail = os.environ.get('ULTR_FUSED_TAIL', '1') != '0'
 
@@ -338,6 +341,7 @@ class BaseAlgorithm(ABC):
             self.model.backward(tb['d_scores'], tb['grads'], tb['sumsq'] if tb['sumsq_valid'] else None)
             if self.ride_metrics:
                 _lib.check(_lib.lib().ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
+        _lib.check(_lib.lib().ultr_loss_flush(_lib.current_stream()), 'ultr_loss_flush')  # no-op if carried
         self._pending = (tb, batch)
 
     def step_reduce(self):

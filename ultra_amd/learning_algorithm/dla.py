@@ -70,7 +70,12 @@ class DLA(BaseAlgorithm):
     def _loss(self, tb, batch, scores):
         L, h = self.rank_list_size, self.hparams
         pg = tb['stats'][self._pg_offset():]
-        _lib.check(_lib.lib().ultr_loss_dla_fwdbwd(
+        # The loss rides with the first launch of the backward pass (ultr_loss_dla_deferred) when nothing needs its
+        # outputs before that: the in-step metrics, which read the list weights, ride with a later launch of the
+        # same pass.  ULTR_LOSS_RIDE=0: a launch of its own.
+        ride = self.ride_loss and self.ride_metrics and not self.side_metrics
+        fn = _lib.lib().ultr_loss_dla_deferred if ride else _lib.lib().ultr_loss_dla_fwdbwd
+        _lib.check(fn(
             _lib.ptr(scores), _lib.ptr(batch.labels), batch.B, L, _lib.ptr(self.prop_params), self.loss_kind,
             self.prob_kind, float(h.max_propensity_weight), _lib.ptr(tb['d_scores']), _lib.ptr(pg),
             _lib.ptr(tb['list_weights']), _lib.ptr(tb['stats']), _lib.ptr(tb['loss_ws']), _lib.current_stream()),
