@@ -42,8 +42,11 @@ extern "C" {
 enum { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1, ULTR_ACT_SELU = 2, ULTR_ACT_TANH = 3, ULTR_ACT_SIGMOID = 4 };
 /* norm hparam (DNN.py:32,70): "layer" or anything else = no normalisation */
 enum { ULTR_NORM_NONE = 0, ULTR_NORM_LAYER = 1 };
-/* click models on the device path (click_models.py:74-116, 194-241) */
-enum { ULTR_CLICK_PBM = 0, ULTR_CLICK_CASCADE = 1, ULTR_CLICK_ORACLE = 2 /* oracle_mode: labels as clicks */ };
+/* click models on the device path (click_models.py:74-116 PBM, :194-241 cascade, :119-191 user browsing model;
+ * TABLE = any model whose click probability is a function of (relevance grade, rank) only, handed over as that
+ * table: the trust-bias model :273-322 and the click-matrix model :244-270) */
+enum { ULTR_CLICK_PBM = 0, ULTR_CLICK_CASCADE = 1, ULTR_CLICK_ORACLE = 2 /* oracle_mode: labels as clicks */,
+       ULTR_CLICK_TABLE = 3, ULTR_CLICK_UBM = 4 };
 /* loss_func hparam (dla.py:129-134, ipw_rank.py:135-143) */
 enum { ULTR_LOSS_SOFTMAX = 0, ULTR_LOSS_SIGMOID = 1 };
 /* logits_to_prob hparam (dla.py:99-101) */
@@ -100,6 +103,18 @@ int ultr_click_pbm(const float* labels, long long n, int L, const double* exam, 
 int ultr_click_cascade(const float* labels, long long n, int L, const double* exam, int n_exam,
                        const double* click_prob, int n_click_prob, const double* uniforms,
                        unsigned long long seed, unsigned int stream_step, float* clicks, void* stream);
+
+/* Any device click model (sampleClicksForOneList of click_models.py:86-93, 144-155, 204-218, 258-266, 291-298).
+ * Tables by model:
+ *   PBM / CASCADE  exam [n_exam] per rank (ranks beyond -> last entry), click_prob [n_click_prob] per grade
+ *   UBM            exam [n_exam][n_exam]: row = rank, column = (rank - rank of the last click above, -1 if none) - 1,
+ *                  ranks >= n_exam read the last row as getExamProb does (:180-191); click_prob per grade
+ *   TABLE          exam [n_click_prob][n_exam] = P(click | grade, rank), float64 products formed by the caller exactly
+ *                  as the model's sampleClick forms them; click_prob is not read (pass exam)
+ * click = [u < P] in float64; a uniform is consumed at every rank; cascade keeps only the first click. */
+int ultr_click_sample(int click_model, const float* labels, long long n, int L, const double* exam, int n_exam,
+                      const double* click_prob, int n_click_prob, const double* uniforms, unsigned long long seed,
+                      unsigned int stream_step, float* clicks, void* stream);
 
 /* ---- batch assembly: ClickSimulationFeed.get_batch (click_simulation_feed.py:107-162) ---
  * Rejection-samples B query lists with >= 1 click (when check_validation) from a data set

@@ -45,32 +45,66 @@ def _clamp_label(label, n):
     return rel if rel < n else n - 1
 
 
-def sample_clicks_one_list(model_name, click_prob, exam_prob, label_list, uniforms):
+def ubm_exam_prob(exam_prob, rank, last_click_rank):
+    """UserBrowsingModel.getExamProb, click_models.py:180-191."""
+    distance = rank - last_click_rank
+    if rank < len(exam_prob):
+        return exam_prob[rank][distance - 1]
+    if distance > rank:
+        return exam_prob[-1][-1]
+    return exam_prob[-1][distance - 1 if distance < len(exam_prob[-1]) - 1 else -2]
+
+
+def trust_bias_click_prob(click_prob, extra, rank, rel):
+    """TrustBiasedModel.getClickProb, click_models.py:316-322."""
+    primitive = click_prob[rel]
+    ep_plus = 1 - (rank + 2) / 100
+    ep_minus = extra['epsilon_1_neg'] / (rank + 1)
+    return primitive * ep_plus + (1 - primitive) * ep_minus
+
+
+def sample_clicks_one_list(model_name, click_prob, exam_prob, label_list, uniforms, extra=None):
     """One call of sampleClicksForOneList with the uniform draws supplied.
 
     PBM: click_models.py:86-116.  Cascade: click_models.py:204-241 (a uniform is
-    consumed at every rank, the output is zeroed after the first click).
+    consumed at every rank, the output is zeroed after the first click).  User browsing
+    model: :144-191 (examination depends on the last click above).  Trust bias: :291-322.
+    Click matrix: :258-266 (click_prob[grade][rank] is the probability itself).
     ``uniforms[r]`` stands for the r-th ``random.random()`` of the call.
     """
     clicks = []
     has_click = False
+    last_click_rank = -1
     for rank, label in enumerate(label_list):
+        if model_name == 'click_matrix_model':
+            rel = int(label) if label > 0 else 0
+            clicks.append(1 if uniforms[rank] < click_prob[rel][rank] else 0)
+            continue
         rel = _clamp_label(label, len(click_prob))
-        exam_p = exam_prob[rank if rank < len(exam_prob) else -1]
-        click = 1 if uniforms[rank] < exam_p * click_prob[rel] else 0
+        if model_name == 'user_browsing_model':
+            exam_p = ubm_exam_prob(exam_prob, rank, last_click_rank)
+        else:
+            exam_p = exam_prob[rank if rank < len(exam_prob) else -1]
+        click_p = trust_bias_click_prob(click_prob, extra, rank, rel) if model_name == 'trust_biased_model' \
+            else click_prob[rel]
+        click = 1 if uniforms[rank] < exam_p * click_p else 0
         if model_name == 'cascade_model':
             clicks.append(0 if has_click else click)
             if click > 0:
                 has_click = True
-        elif model_name == 'position_biased_model':
+        elif model_name in ('position_biased_model', 'trust_biased_model'):
             clicks.append(click)
+        elif model_name == 'user_browsing_model':
+            clicks.append(click)
+            if click > 0:
+                last_click_rank = rank
         else:
             raise ValueError('click model %s is outside the hot path' % model_name)
     return clicks
 
 
 def get_batch_sequential(initial_list, labels, rank_list_size, batch_size, model_name,
-                         click_prob, exam_prob, uniforms, check_validation=True):
+                         click_prob, exam_prob, uniforms, check_validation=True, extra=None):
     """click_simulation_feed.py:107-143 with the Python RNG stream supplied.
 
     ``uniforms`` is a flat float64 sequence standing for successive
@@ -89,7 +123,7 @@ def get_batch_sequential(initial_list, labels, rank_list_size, batch_size, model
         i = int(uniforms[pos] * length)
         label_list = [0 if initial_list[i][x] < 0 else labels[i][x] for x in range(L)]  # :80-82
         c = sample_clicks_one_list(model_name, click_prob, exam_prob, label_list,
-                                   uniforms[pos + 1:pos + 1 + L])
+                                   uniforms[pos + 1:pos + 1 + L], extra)
         pos += 1 + L
         n_cand += 1
         if check_validation and sum(c) == 0:
@@ -147,7 +181,7 @@ def philox_uniforms(seed, step, slot, attempt, n):
 
 
 def get_batch_slots(initial_list, labels, rank_list_size, batch_size, model_name, click_prob,
-                    exam_prob, seed, step, slot_base=0, max_attempts=100, check_validation=True):
+                    exam_prob, seed, step, slot_base=0, max_attempts=100, check_validation=True, extra=None):
     """Per-slot rejection sampling: slot s retries with attempt t = 0,1,.. on its own stream.
 
     Distributionally identical to click_simulation_feed.py:131-137 (i.i.d.
@@ -162,7 +196,7 @@ def get_batch_slots(initial_list, labels, rank_list_size, batch_size, model_name
             u = philox_uniforms(seed, step, slot_base + s, t, 1 + L)
             i = int(u[0] * length)
             label_list = [0 if initial_list[i][x] < 0 else labels[i][x] for x in range(L)]
-            c = sample_clicks_one_list(model_name, click_prob, exam_prob, label_list, u[1:])
+            c = sample_clicks_one_list(model_name, click_prob, exam_prob, label_list, u[1:], extra)
             if (not check_validation) or sum(c) > 0 or t == max_attempts - 1:
                 break
         idxs.append(i)

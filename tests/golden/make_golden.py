@@ -36,6 +36,10 @@ def click_goldens(cm):
         'cascade_json': ('example/ClickModel/cascade_0.1_1.0_4_1.0.json', None),
         'pbm_eta2': (None, ('PositionBiasedModel', (0.1, 0.9, 4, 2.0))),
         'cascade_ctor': (None, ('CascadeModel', (0.05, 1.0, 2, 1.0))),
+        'ubm_json': ('example/ClickModel/ubm_0.1_1_4_1.0.json', None),
+        'ubm_eta05': (None, ('UserBrowsingModel', (0.1, 1.0, 4, 0.5))),
+        'trust_bias_json': ('example/ClickModel/trust_bias.json', None),
+        'click_matrix_json': ('example/ClickModel/click_matrix_tiangong.json', None),
     }
     rng = random.Random(20241110)
     for name, (path, ctor) in models.items():
@@ -46,10 +50,14 @@ def click_goldens(cm):
         cases = []
         for case in range(40):
             L = rng.choice([1, 4, 9, 10, 10, 10, 12, 15])
+            if model.model_name == 'click_matrix_model':
+                L = min(L, 10)          # click_prob[grade][rank] has 10 ranks: longer lists raise IndexError
             labels = [rng.choice([0, 0, 0, 1, 1, 2, 3, 4]) for _ in range(L)]
+            if model.model_name == 'click_matrix_model':
+                labels = [min(x, len(model.click_prob) - 1) for x in labels]  # grades beyond the matrix raise too
             if case % 7 == 3:
                 labels[0] = -1          # negative -> grade 0   (click_models.py:108)
-            if case % 7 == 5:
+            if case % 7 == 5 and model.model_name != 'click_matrix_model':
                 labels[-1] = 9          # beyond table -> last  (click_models.py:110-111)
             seed = rng.randrange(1 << 30)
             random.seed(seed)
@@ -60,7 +68,8 @@ def click_goldens(cm):
                           'clicks': [float(c) for c in clicks],
                           'exam_p': [float(x) for x in exam_p], 'click_p': click_p})
         out.append({'name': name, 'model_name': model.model_name, 'eta': model.eta,
-                    'click_prob': model.click_prob, 'exam_prob': model.exam_prob, 'cases': cases})
+                    'click_prob': model.click_prob, 'exam_prob': model.exam_prob,
+                    'extra': getattr(model, 'extra', None), 'cases': cases})
     # setClickProb known answers (click_models.py:51-57)
     tables = []
     for args in [(0.1, 1.0, 4), (0.1, 0.9, 4), (0.0, 1.0, 1), (0.05, 1.0, 2)]:
@@ -117,6 +126,8 @@ def main():
     json.dump(click_goldens(cm), open(os.path.join(HERE, 'click_goldens.json'), 'w'), indent=1)
     json.dump(hparams_goldens(hp), open(os.path.join(HERE, 'hparams_goldens.json'), 'w'), indent=1)
     for rel in ['example/ClickModel/pbm_0.1_1.0_4_1.0.json', 'example/ClickModel/cascade_0.1_1.0_4_1.0.json',
+                'example/ClickModel/ubm_0.1_1_4_1.0.json', 'example/ClickModel/trust_bias.json',
+                'example/ClickModel/click_matrix_tiangong.json',
                 'example/PropensityEstimator/randomized_pbm_0.1_1.0_4_1.0.json']:
         shutil.copy(os.path.join(REF, rel), os.path.join(HERE, os.path.basename(rel)))
     # toy data (data files only): ULTRA format from tests/data, libsvm format from example/toy/data

@@ -57,18 +57,56 @@ def stream(L):
 # ------------------------------------------------------------------------------------------------
 # click kernels
 # ------------------------------------------------------------------------------------------------
+def _device_click_model(desc, Ls):
+    """(kind, exam tensor, n_exam, click_prob tensor) as the feeds upload them (click_models.device_tables)."""
+    from ultra_amd.utils import click_models as cm
+    if desc['model_name'] == 'oracle':
+        return 2, dev([1.0], torch.float64), 1, dev([1.0], torch.float64)
+    d = {k: desc[k] for k in ('model_name', 'eta', 'click_prob', 'exam_prob')}
+    if desc.get('extra') is not None:
+        d['extra'] = desc['extra']
+    kind, exam, n_exam, cp = cm.loadModelFromJson(d).device_tables(Ls)
+    return kind, dev(exam, torch.float64), n_exam, dev(cp, torch.float64)
+
+
 def test_click_kernels_bit_exact_on_reference_goldens(L):
+    """Every click model of the reference (PBM, cascade, user browsing, trust bias, click matrix) on the clicks the
+    reference module itself returned for the same labels and uniform draws."""
     g = load_json('click_goldens.json')
+    assert len(g['models']) == 8
     for model in g['models']:
-        fn = L.lib().ultr_click_cascade if model['model_name'] == 'cascade_model' else L.lib().ultr_click_pbm
-        exam, cp = dev(model['exam_prob'], torch.float64), dev(model['click_prob'], torch.float64)
         for case in model['cases']:
             n = len(case['labels'])
+            kind, exam, n_exam, cp = _device_click_model(model, n)
             lab, u = dev([case['labels']], torch.float32), dev([case['uniforms']], torch.float64)
             out = torch.empty((1, n), dtype=torch.float32, device='cuda')
-            L.check(fn(L.ptr(lab), 1, n, L.ptr(exam), exam.numel(), L.ptr(cp), cp.numel(), L.ptr(u), 0, 0, L.ptr(out),
-                       stream(L)), 'click')
+            L.check(L.lib().ultr_click_sample(kind, L.ptr(lab), 1, n, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), L.ptr(u),
+                                              0, 0, L.ptr(out), stream(L)), 'click')
             assert out.cpu().numpy()[0].tolist() == case['clicks'], (model['name'], case['seed'])
+            if kind <= 1:  # the two original entry points
+                fn = L.lib().ultr_click_cascade if kind == 1 else L.lib().ultr_click_pbm
+                out2 = torch.empty_like(out)
+                L.check(fn(L.ptr(lab), 1, n, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), L.ptr(u), 0, 0, L.ptr(out2),
+                           stream(L)), 'click')
+                assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('model_file', ['ubm_0.1_1_4_1.0.json', 'trust_bias.json', 'click_matrix_tiangong.json'])
+def test_click_kernel_bulk_other_models(L, model_file):
+    g = load_json(model_file)
+    rng = np.random.RandomState(13)
+    n, Ls = 4000, 10 if 'matrix' in model_file else 13   # 13 > 10: ranks beyond the examination tables
+    n_grades = len(g['click_prob'])
+    labels = rng.choice(n_grades if 'matrix' in model_file else n_grades + 1, size=(n, Ls)).astype(np.float32)
+    labels[::17, 0] = -1.0
+    u = rng.random_sample((n, Ls)) * 0.6
+    kind, exam, n_exam, cp = _device_click_model(g, Ls)
+    out = torch.empty((n, Ls), dtype=torch.float32, device='cuda')
+    L.check(L.lib().ultr_click_sample(kind, L.ptr(dev(labels)), n, Ls, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(),
+                                      L.ptr(dev(u)), 0, 0, L.ptr(out), stream(L)), 'click')
+    want = np.array([O.sample_clicks_one_list(g['model_name'], g['click_prob'], g['exam_prob'], list(labels[i]), u[i],
+                                              g.get('extra')) for i in range(n)], dtype=np.float32)
+    assert np.array_equal(out.cpu().numpy(), want) and 0.02 < want.mean() < 0.7
 
 
 @pytest.mark.parametrize('cascade', [False, True])
@@ -109,8 +147,7 @@ def test_click_kernels_bulk_and_philox(L, cascade):
 def _assemble(L, data, B, Ls, model, mode, seed=0, step=0, slot_base=0, u=None, slot_start=0, check=1,
               step_ctr=None, out=None, max_attempts=100):
     il, lab = dev(data.initial_list, torch.int32), dev(data.labels, torch.float32)
-    exam, cp = dev(model['exam_prob'], torch.float64), dev(model['click_prob'], torch.float64)
-    kind = {'position_biased_model': 0, 'cascade_model': 1, 'oracle': 2}[model['model_name']]
+    kind, exam, n_exam, cp = _device_click_model(model, Ls)
     if out is None:
         out = (torch.full((Ls, B), -7, dtype=torch.int32, device='cuda'),
                torch.full((Ls, B), -7.0, dtype=torch.float32, device='cuda'),
@@ -119,17 +156,20 @@ def _assemble(L, data, B, Ls, model, mode, seed=0, step=0, slot_base=0, u=None, 
     n_cand = 0 if u is None else u.shape[0]
     n_rows = data.features.shape[0]
     L.check(L.lib().ultr_batch_assemble(
-        L.ptr(il), L.ptr(lab), il.shape[0], il.shape[1], Ls, B, kind, L.ptr(exam), exam.numel(), L.ptr(cp), cp.numel(),
+        L.ptr(il), L.ptr(lab), il.shape[0], il.shape[1], Ls, B, kind, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(),
         mode, seed, step, L.ptr(step_ctr), slot_base, L.ptr(ud), n_cand, slot_start, check, max_attempts, n_rows,
         L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), stream(L)), 'assemble')
     torch.cuda.synchronize()
     return out
 
 
-@pytest.mark.parametrize('model_file', ['pbm_0.1_1.0_4_1.0.json', 'cascade_0.1_1.0_4_1.0.json'])
+@pytest.mark.parametrize('model_file', ['pbm_0.1_1.0_4_1.0.json', 'cascade_0.1_1.0_4_1.0.json', 'ubm_0.1_1_4_1.0.json',
+                                        'trust_bias.json', 'click_matrix_tiangong.json'])
 def test_batch_assemble_sequential_bit_exact(L, model_file):
     model = load_json(model_file)
     data = SyntheticData(300, 12, 8, seed=21, pad_frac=0.3)
+    if 'matrix' in model_file:
+        data.labels = np.minimum(data.labels, len(model['click_prob']) - 1)  # grades beyond the matrix raise in the reference
     Ls, B = 10, 256
     rng = np.random.RandomState(5)
     n_cand = 3000  # > 1024: several rounds of the single-workgroup loop
@@ -137,7 +177,7 @@ def test_batch_assemble_sequential_bit_exact(L, model_file):
     docids, clicks, idx, info = _assemble(L, data, B, Ls, model, 1, u=u)
     want_idx, want_clicks, want_n = O.get_batch_sequential(
         data.initial_list, data.labels, Ls, B, model['model_name'], model['click_prob'], model['exam_prob'],
-        u.reshape(-1), True)
+        u.reshape(-1), True, model.get('extra'))
     assert info.cpu().tolist()[:2] == [want_n, B]
     assert idx.cpu().tolist() == want_idx
     assert np.array_equal(clicks.cpu().numpy().T, np.array(want_clicks, dtype=np.float32))
@@ -149,6 +189,22 @@ def test_batch_assemble_sequential_bit_exact(L, model_file):
     assert consumed == 200 and 0 < filled < B
     out = _assemble(L, data, B, Ls, model, 1, u=u[200:], slot_start=filled, out=out)
     assert out[3].cpu().tolist()[:2] == [want_n - 200, B] and out[2].cpu().tolist() == want_idx
+
+
+@pytest.mark.parametrize('model_file,Ls', [('ubm_0.1_1_4_1.0.json', 10), ('ubm_0.1_1_4_1.0.json', 12),
+                                           ('trust_bias.json', 10), ('ubm_0.1_1_4_1.0.json', 20)])
+def test_batch_assemble_philox_other_models(L, model_file, Ls):
+    """The wave-per-slot assembly with the models whose click probability is not exam[rank] * click_prob[grade]: the
+    user browsing model resolves its ranks in order inside the wave (every attempt of a round keeps its own last click)."""
+    model = load_json(model_file)
+    data = SyntheticData(400, 24, 8, seed=23, pad_frac=0.2)
+    B, seed, step = 300, 0xABCDEF12345, 5
+    docids, clicks, idx, info = _assemble(L, data, B, Ls, model, 0, seed=seed, step=step)
+    w_idx, w_clicks, w_att = O.get_batch_slots(data.initial_list, data.labels, Ls, 48, model['model_name'],
+                                               model['click_prob'], model['exam_prob'], seed, step, extra=model.get('extra'))
+    assert idx.cpu().tolist()[:48] == w_idx
+    assert np.array_equal(clicks.cpu().numpy().T[:48], np.array(w_clicks, dtype=np.float32))
+    assert (clicks.sum(dim=0) > 0).all() and max(w_att) > 1
 
 
 def test_batch_assemble_philox_slots_bit_exact_and_dp_invariant(L):

@@ -24,10 +24,11 @@ def test_click_oracle_matches_reference_goldens():
     for model in g['models']:
         for case in model['cases']:
             got = O.sample_clicks_one_list(model['model_name'], model['click_prob'], model['exam_prob'],
-                                           case['labels'], case['uniforms'])
+                                           case['labels'], case['uniforms'], model.get('extra'))
             assert [float(c) for c in got] == case['clicks'], (model['name'], case)
             n += 1
-    assert n == 160
+    assert n == 320 and {m['model_name'] for m in g['models']} == {
+        'position_biased_model', 'cascade_model', 'user_browsing_model', 'trust_biased_model', 'click_matrix_model'}
     pbm = [m for m in g['models'] if m['name'] == 'pbm_json'][0]
     random.seed(0)
     u = [random.random() for _ in range(10)]
@@ -50,8 +51,11 @@ def test_host_click_models_match_goldens():
     from ultra_amd.utils import click_models as cm
     g = load_json('click_goldens.json')
     for model in g['models']:
-        m = cm.loadModelFromJson({'model_name': model['model_name'], 'eta': model['eta'],
-                                  'click_prob': model['click_prob'], 'exam_prob': model['exam_prob']})
+        desc = {'model_name': model['model_name'], 'eta': model['eta'],
+                'click_prob': model['click_prob'], 'exam_prob': model['exam_prob']}
+        if model.get('extra') is not None:
+            desc['extra'] = model['extra']
+        m = cm.loadModelFromJson(desc)
         for case in model['cases']:
             random.seed(case['seed'])
             clicks, exam_p, click_p = m.sampleClicksForOneList(list(case['labels']))
@@ -61,8 +65,42 @@ def test_host_click_models_match_goldens():
         assert cm.PositionBiasedModel(*t['args'], 1.0).click_prob == t['click_prob']
     for t in g['exam_tables']:
         assert cm.PositionBiasedModel(0.1, 1.0, 4, t['eta']).exam_prob == t['exam_prob']
-    with pytest.raises(NotImplementedError):
-        cm.loadModelFromJson({'model_name': 'user_browsing_model', 'eta': 1, 'click_prob': [], 'exam_prob': []})
+    # an unknown model name falls back to the position-biased model (click_models.py:8)
+    assert cm.loadModelFromJson({'model_name': 'nonesuch', 'eta': 1, 'click_prob': [0.1], 'exam_prob': [1.0]}
+                                ).model_name == 'position_biased_model'
+
+
+def test_device_click_tables_hold_the_reference_thresholds():
+    """What the feeds upload (device_tables) against the products sampleClick compares a uniform with: the exam_p and
+    click_p the reference returned for every golden case, multiplied in float64 exactly as click_models.py does."""
+    from ultra_amd.utils import click_models as cm
+    g = load_json('click_goldens.json')
+    for model in g['models']:
+        desc = {k: model[k] for k in ('model_name', 'eta', 'click_prob', 'exam_prob')}
+        if model.get('extra') is not None:
+            desc['extra'] = model['extra']
+        m = cm.loadModelFromJson(desc)
+        kind, exam, n_exam, cp = m.device_tables(10)
+        assert kind == {'position_biased_model': 0, 'cascade_model': 1, 'user_browsing_model': 4,
+                        'trust_biased_model': 3, 'click_matrix_model': 3}[model['model_name']]
+        if model['model_name'] == 'trust_biased_model':
+            assert n_exam == 10 and len(exam) == len(model['click_prob']) * 10
+            for case in model['cases']:
+                for r, lab in enumerate(case['labels'][:10]):
+                    grade = min(max(int(lab), 0), len(model['click_prob']) - 1)
+                    assert exam[grade * n_exam + r] == case['exam_p'][r] * case['click_p'][r]
+            wide = m.device_tables(15)     # the trust term keeps changing beyond the examination table
+            assert wide[2] == 15 and wide[1][14] == m.getExamProb(14) * m.getClickProb(14, 0)
+        elif model['model_name'] == 'user_browsing_model':
+            assert n_exam == 10 and len(exam) == 100
+            assert all(exam[r * 10 + d] == model['exam_prob'][r][d] for r in range(10) for d in range(r + 1))
+        elif model['model_name'] == 'click_matrix_model':
+            assert n_exam == 10 and exam == [x for row in model['click_prob'] for x in row]
+            with pytest.raises(IndexError):
+                m.device_tables(11)
+    with pytest.raises(ValueError):
+        cm.loadModelFromJson({'model_name': 'user_browsing_model', 'eta': 1, 'click_prob': [0.1, 1.0],
+                              'exam_prob': [[1.0], [1.0]]}).device_tables(10)
 
 
 def test_hparams_match_reference_goldens():

@@ -15,7 +15,7 @@ ULTR_MAX_LIST = 64
 
 ACT = {'elu': 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid': 4}
 NORM_NONE, NORM_LAYER = 0, 1
-CLICK_PBM, CLICK_CASCADE, CLICK_ORACLE = 0, 1, 2
+CLICK_PBM, CLICK_CASCADE, CLICK_ORACLE, CLICK_TABLE, CLICK_UBM = 0, 1, 2, 3, 4
 LOSS_SOFTMAX, LOSS_SIGMOID = 0, 1
 PROB_SOFTMAX, PROB_SIGMOID = 0, 1
 OPT_ADAGRAD, OPT_SGD = 0, 1
@@ -59,6 +59,7 @@ SIGNATURES = {
     'ultr_profile_report': (_I, [ctypes.c_char_p, _I]),
     'ultr_ln_row_stats': (_I, [_P, _LL, _I, _I, _F, _P, _P]),
     'ultr_click_pbm': (_I, [_P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),
+    'ultr_click_sample': (_I, [_I, _P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),
     'ultr_click_cascade': (_I, [_P, _LL, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _P]),
     'ultr_batch_assemble': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _ULL, _U, _P, _U, _P, _I, _I,
                                  _I, _I, _I, _P, _P, _P, _P, _P]),

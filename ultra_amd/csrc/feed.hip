@@ -26,8 +26,7 @@ struct PhiloxDraws {
 };
 
 // One thread per list.  labels/clicks/uniforms are list-major [n][L].
-template <bool CASCADE>
-__global__ void __launch_bounds__(256) click_kernel(const float* __restrict__ labels, long long n, int L,
+__global__ void __launch_bounds__(256) click_kernel(int model, const float* __restrict__ labels, long long n, int L,
                                                     ClickTables t, const double* __restrict__ uniforms,
                                                     unsigned long long seed, unsigned int step,
                                                     float* __restrict__ clicks) {
@@ -36,12 +35,14 @@ __global__ void __launch_bounds__(256) click_kernel(const float* __restrict__ la
   PhiloxDraws ph;
   ph.init((uint32_t)i, 0u, step, seed);
   bool has_click = false;
+  int last = -1;
   for (int r = 0; r < L; ++r) {
     const float lab = labels[i * L + r];
     const double u = uniforms ? uniforms[i * L + r] : ph.draw(r);  // a draw at EVERY rank (click_models.py:208)
-    const bool c = u < click_threshold(t, r, lab);
-    clicks[i * L + r] = (c && !(CASCADE && has_click)) ? 1.f : 0.f;
+    const bool c = u < click_threshold(t, model, r, lab, last);
+    clicks[i * L + r] = (c && !(model == ULTR_CLICK_CASCADE && has_click)) ? 1.f : 0.f;
     has_click = has_click || c;
+    if (c) last = r;
   }
 }
 
@@ -56,6 +57,7 @@ __device__ __forceinline__ unsigned long long eval_candidate(DrawFn&& draw, cons
   *out_i = i;
   unsigned long long mask = 0ull;
   bool has_click = false;
+  int last = -1;
   for (int r = 0; r < L; ++r) {
     const int doc = initial_list[(long long)i * Lmax + r];
     const float lab = doc < 0 ? 0.f : labels[(long long)i * Lmax + r];  // :80-82
@@ -63,9 +65,10 @@ __device__ __forceinline__ unsigned long long eval_candidate(DrawFn&& draw, cons
       if (lab != 0.f) mask |= (1ull << r);
       continue;
     }
-    const bool c = draw(1 + r) < click_threshold(t, r, lab);
+    const bool c = draw(1 + r) < click_threshold(t, click_model, r, lab, last);
     if (c && !(click_model == ULTR_CLICK_CASCADE && has_click)) mask |= (1ull << r);
     has_click = has_click || c;
+    if (c) last = r;
   }
   return mask;
 }
@@ -142,42 +145,47 @@ __global__ void __launch_bounds__(1024) assemble_sequential_kernel(
 
 using namespace ultr;
 
-static int click_common(bool cascade, const float* labels, long long n, int L, const double* exam, int n_exam,
-                        const double* click_prob, int n_cp, const double* uniforms, unsigned long long seed,
-                        unsigned int step, float* clicks, void* stream) {
-  ULTR_REQUIRE(labels && clicks && exam && click_prob, ULTR_EINVAL, "ultr_click: null pointer");
-  ULTR_REQUIRE(n >= 0 && L > 0 && n_exam > 0 && n_cp > 0, ULTR_EINVAL, "ultr_click: bad sizes n=%lld L=%d", n, L);
-  ULTR_REQUIRE(n < (1ll << 32), ULTR_ELIMIT, "ultr_click: n=%lld exceeds the 32-bit Philox list counter", n);
+static int click_model_ok(const char* who, int click_model, int n_exam, int n_cp) {
+  ULTR_REQUIRE(click_model == ULTR_CLICK_PBM || click_model == ULTR_CLICK_CASCADE || click_model == ULTR_CLICK_ORACLE ||
+                   click_model == ULTR_CLICK_TABLE || click_model == ULTR_CLICK_UBM,
+               ULTR_EINVAL, "%s: click model %d is not on the device path", who, click_model);
+  ULTR_REQUIRE(n_exam > 0 && n_cp > 0, ULTR_EINVAL, "%s: empty click tables (n_exam=%d, n_click_prob=%d)", who, n_exam, n_cp);
+  ULTR_REQUIRE(click_model != ULTR_CLICK_UBM || n_exam >= 2, ULTR_EINVAL,
+               "%s: the user browsing model needs at least two rows of examination probabilities", who);
+  return ULTR_OK;
+}
+
+extern "C" int ultr_click_sample(int click_model, const float* labels, long long n, int L, const double* exam,
+                                 int n_exam, const double* click_prob, int n_click_prob, const double* uniforms,
+                                 unsigned long long seed, unsigned int stream_step, float* clicks, void* stream) {
+  ULTR_REQUIRE(labels && clicks && exam && click_prob, ULTR_EINVAL, "ultr_click_sample: null pointer");
+  ULTR_REQUIRE(n >= 0 && L > 0, ULTR_EINVAL, "ultr_click_sample: bad sizes n=%lld L=%d", n, L);
+  int rc = click_model_ok("ultr_click_sample", click_model, n_exam, n_click_prob);
+  if (rc) return rc;
+  ULTR_REQUIRE(click_model != ULTR_CLICK_ORACLE, ULTR_EINVAL, "ultr_click_sample: oracle mode copies labels, nothing to sample");
+  ULTR_REQUIRE(n < (1ll << 32), ULTR_ELIMIT, "ultr_click_sample: n=%lld exceeds the 32-bit Philox list counter", n);
   if (n == 0) return ULTR_OK;
-  ClickTables t{exam, n_exam, click_prob, n_cp};
-  const dim3 grid((unsigned)cdiv(n, 256));
-  if (cascade)
-    {
-      ultr::ProfScope prof_("click_kernel", as_stream(stream));
-      hipLaunchKernelGGL(click_kernel<true>, grid, dim3(256), 0, as_stream(stream), labels, n, L, t, uniforms, seed, step,
-                       clicks);
-    }
-  else
-    {
-      ultr::ProfScope prof_("click_kernel", as_stream(stream));
-      hipLaunchKernelGGL(click_kernel<false>, grid, dim3(256), 0, as_stream(stream), labels, n, L, t, uniforms, seed,
-                       step, clicks);
-    }
+  ClickTables t{exam, n_exam, click_prob, n_click_prob};
+  {
+    ultr::ProfScope prof_("click_kernel", as_stream(stream));
+    hipLaunchKernelGGL(click_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), click_model, labels, n,
+                       L, t, uniforms, seed, stream_step, clicks);
+  }
   return check_launch("click_kernel");
 }
 
 extern "C" int ultr_click_pbm(const float* labels, long long n, int L, const double* exam, int n_exam,
                               const double* click_prob, int n_click_prob, const double* uniforms,
                               unsigned long long seed, unsigned int stream_step, float* clicks, void* stream) {
-  return click_common(false, labels, n, L, exam, n_exam, click_prob, n_click_prob, uniforms, seed, stream_step, clicks,
-                      stream);
+  return ultr_click_sample(ULTR_CLICK_PBM, labels, n, L, exam, n_exam, click_prob, n_click_prob, uniforms, seed,
+                           stream_step, clicks, stream);
 }
 
 extern "C" int ultr_click_cascade(const float* labels, long long n, int L, const double* exam, int n_exam,
                                   const double* click_prob, int n_click_prob, const double* uniforms,
                                   unsigned long long seed, unsigned int stream_step, float* clicks, void* stream) {
-  return click_common(true, labels, n, L, exam, n_exam, click_prob, n_click_prob, uniforms, seed, stream_step, clicks,
-                      stream);
+  return ultr_click_sample(ULTR_CLICK_CASCADE, labels, n, L, exam, n_exam, click_prob, n_click_prob, uniforms, seed,
+                           stream_step, clicks, stream);
 }
 
 namespace ultr {
@@ -203,10 +211,7 @@ static int assemble_checks(const int* initial_list, const float* labels, int Q, 
   ULTR_REQUIRE(Lmax >= L, ULTR_EINVAL,
                "Input ranklist length must be no less than the required list size, %d != %d.", Lmax, L);
   ULTR_REQUIRE(L <= ULTR_MAX_LIST, ULTR_ELIMIT, "ultr_batch_assemble: L=%d > %d", L, ULTR_MAX_LIST);
-  ULTR_REQUIRE(click_model == ULTR_CLICK_PBM || click_model == ULTR_CLICK_CASCADE || click_model == ULTR_CLICK_ORACLE,
-               ULTR_EINVAL,
-               "ultr_batch_assemble: click model %d is not on the device path", click_model);
-  return ULTR_OK;
+  return click_model_ok("ultr_batch_assemble", click_model, n_exam, n_click_prob);
 }
 
 static AssembleArgs assemble_args(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,

@@ -7,6 +7,11 @@
 
 namespace ultr {
 
+// exam / click_prob by click model:
+//   PBM, cascade: exam [n_exam] per rank, click_prob [n_cp] per relevance grade (click_models.py:86-116, 204-241)
+//   UBM:          exam [n_exam][n_exam], row = rank, column = distance to the last click - 1 (:125-142, 180-191)
+//   TABLE:        exam [n_cp][n_exam] = P(click | grade, rank) formed on the host in float64 (the trust-bias model
+//                 :304-322 and the click-matrix model :258-266 are functions of (grade, rank) only); click_prob unused
 struct ClickTables {
   const double* exam;
   int n_exam;
@@ -14,10 +19,25 @@ struct ClickTables {
   int n_cp;
 };
 
-// click probability of (rank, label) in float64, click_models.py:105-116
-__device__ __forceinline__ double click_threshold(const ClickTables& t, int rank, float label) {
+// click probability of (rank, label) in float64, click_models.py:105-116; `last` = rank of the last click above
+// this rank (-1: none), read by the user browsing model only (:170-191)
+__device__ __forceinline__ double click_threshold(const ClickTables& t, int model, int rank, float label, int last) {
   int rel = label > 0.f ? (int)label : 0;           // int() truncation, negatives -> 0
   rel = rel < t.n_cp ? rel : t.n_cp - 1;            // beyond the table -> last entry
+  if (model == ULTR_CLICK_TABLE) return t.exam[(long long)rel * t.n_exam + (rank < t.n_exam ? rank : t.n_exam - 1)];
+  if (model == ULTR_CLICK_UBM) {
+    const int n = t.n_exam, dist = rank - last;
+    int row = n - 1, col;
+    if (rank < n) {
+      row = rank;
+      col = dist - 1;
+    } else if (dist > rank) {                        // no click so far: exam_prob[-1][-1]
+      col = n - 1;
+    } else {
+      col = dist < n - 1 ? dist - 1 : n - 2;         // :188-190
+    }
+    return t.exam[row * n + col] * t.click_prob[rel];
+  }
   const int r = rank < t.n_exam ? rank : t.n_exam - 1;
   return t.exam[r] * t.click_prob[rel];
 }
@@ -88,7 +108,9 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
       bool c = false;
       doc = -1;
       lab = 0.f;
-      if (pos < L && a < max_attempts) {
+      double u = 2.0;
+      const bool live = pos < L && a < max_attempts;
+      if (live) {
         doc = initial_list[(long long)i * Lmax + pos];
         lab = doc < 0 ? 0.f : labels[(long long)i * Lmax + pos];  // :80-82
         if (click_model == ULTR_CLICK_ORACLE) {
@@ -96,8 +118,19 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
         } else {
           const int d = 1 + pos;  // draws 1..L are the click draws (:87)
           const Philox4 bd = philox4x32_10(slot, (uint32_t)a, (uint32_t)(d >> 1), step, k0, k1);
-          const double u = (d & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
-          c = u < click_threshold(t, pos, lab);
+          u = (d & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+          if (click_model != ULTR_CLICK_UBM) c = u < click_threshold(t, click_model, pos, lab, -1);
+        }
+      }
+      if (click_model == ULTR_CLICK_UBM) {
+        // the examination probability of a rank depends on where the last click above it was (:144-155): the ranks
+        // of an attempt resolve in order, one wave-uniform round each, every lane keeping its own attempt's last click
+        int last_click = -1;
+        for (int r = 0; r < L; ++r) {
+          const bool cr = live && pos == r && u < click_threshold(t, click_model, pos, lab, last_click);
+          const unsigned long long br = __ballot(cr);
+          if ((br >> (ai * P + r)) & 1ull) last_click = r;
+          c = c || cr;
         }
       }
       const unsigned long long bal = __ballot(c);

@@ -75,9 +75,9 @@ class ClickSimulationFeed(BaseInputFeed):
 
     def _upload_tables(self):
         if self.click_model is None:
-            self.kind, exam, cp = _lib.CLICK_ORACLE, [1.0], [1.0]
+            self.kind, exam, self.n_exam, cp = _lib.CLICK_ORACLE, [1.0], 1, [1.0]
         else:
-            self.kind, exam, cp = self.click_model.device_kind, self.click_model.exam_prob, self.click_model.click_prob
+            self.kind, exam, self.n_exam, cp = self.click_model.device_tables(self.rank_list_size)
         self.exam = torch.tensor(exam, dtype=torch.float64, device=self.device)
         self.click_prob = torch.tensor(cp, dtype=torch.float64, device=self.device)
 
@@ -99,7 +99,7 @@ class ClickSimulationFeed(BaseInputFeed):
     def _assemble(self, dd, o, B, mode, uniforms=None, n_cand=0, slot_start=0, check_validation=True):
         _lib.check(_lib.lib().ultr_batch_assemble(
             _lib.ptr(dd.initial_list), _lib.ptr(dd.labels), dd.Q, dd.Lmax, self.rank_list_size, B, self.kind,
-            _lib.ptr(self.exam), self.exam.numel(), _lib.ptr(self.click_prob), self.click_prob.numel(), mode,
+            _lib.ptr(self.exam), self.n_exam, _lib.ptr(self.click_prob), self.click_prob.numel(), mode,
             int(self.hparams.seed) & 0xFFFFFFFFFFFFFFFF, 0, _lib.ptr(self.step_ctr) if mode == 0 else None,
             parallel.slot_base(self.rank, B), _lib.ptr(uniforms), n_cand, slot_start, 1 if check_validation else 0,
             self.MAX_SAMPLE_ROUND_NUM, dd.n_rows, _lib.ptr(o['docids']), _lib.ptr(o['clicks']), _lib.ptr(o['idx']),
@@ -110,7 +110,7 @@ class ClickSimulationFeed(BaseInputFeed):
         launch (``ultr_batch_assemble_deferred``); if no backward pass comes first, the next call launches it."""
         _lib.check(_lib.lib().ultr_batch_assemble_deferred(
             _lib.ptr(dd.initial_list), _lib.ptr(dd.labels), dd.Q, dd.Lmax, self.rank_list_size, B, self.kind,
-            _lib.ptr(self.exam), self.exam.numel(), _lib.ptr(self.click_prob), self.click_prob.numel(),
+            _lib.ptr(self.exam), self.n_exam, _lib.ptr(self.click_prob), self.click_prob.numel(),
             int(self.hparams.seed) & 0xFFFFFFFFFFFFFFFF, 0, _lib.ptr(self.step_ctr), parallel.slot_base(self.rank, B),
             1 if check_validation else 0, self.MAX_SAMPLE_ROUND_NUM, dd.n_rows, _lib.ptr(o['docids']),
             _lib.ptr(o['clicks']), _lib.ptr(o['idx']), _lib.ptr(self.info), _lib.current_stream()),
@@ -181,7 +181,7 @@ class ClickSimulationFeed(BaseInputFeed):
             if self.global_batch_count % self.hparams.dynamic_bias_step_interval == 0:
                 self.click_model.eta += self.hparams.dynamic_bias_eta_change
                 self.click_model.setExamProb(self.click_model.eta)  # rebuilt from the built-in table (q5)
-                self.exam.copy_(torch.tensor(self.click_model.exam_prob, dtype=torch.float64))
+                self.exam.copy_(torch.tensor(self.click_model.device_tables(self.rank_list_size)[1], dtype=torch.float64))
                 print('Dynamically change bias severity eta to %.3f' % self.click_model.eta)
         return input_feed, info_map
 
@@ -197,9 +197,9 @@ class ClickSimulationFeed(BaseInputFeed):
             out = torch.empty_like(lab_nl)
             u = torch.tensor([[random.random() for _ in range(L)] for _ in range(n)], dtype=torch.float64,
                              device=self.device)
-            fn = _lib.lib().ultr_click_cascade if self.kind == _lib.CLICK_CASCADE else _lib.lib().ultr_click_pbm
-            _lib.check(fn(_lib.ptr(lab_nl), n, L, _lib.ptr(self.exam), self.exam.numel(), _lib.ptr(self.click_prob),
-                          self.click_prob.numel(), _lib.ptr(u), 0, 0, _lib.ptr(out), _lib.current_stream()), 'ultr_click')
+            _lib.check(_lib.lib().ultr_click_sample(
+                self.kind, _lib.ptr(lab_nl), n, L, _lib.ptr(self.exam), self.n_exam, _lib.ptr(self.click_prob),
+                self.click_prob.numel(), _lib.ptr(u), 0, 0, _lib.ptr(out), _lib.current_stream()), 'ultr_click_sample')
             clicks = out.t().contiguous()
         if check_validation:
             keep = clicks.sum(dim=0) != 0
