@@ -129,7 +129,9 @@ int ultr_click_sample(int click_model, const float* labels, long long n, int L, 
  *   slot_start.. ; info[0] = candidates consumed, info[1] = slots filled so far.
  * step_ctr (mode 0, may be NULL): device uint32 added to `step` and incremented once per call by
  *   the last workgroup to finish -- kernel arguments are frozen in a hipGraph, this is not.
- * info: int32[4] device, zero-initialised: {consumed, filled, total_attempts, arrival counter}. */
+ * info: int32[36] device, zero-initialised: {consumed, filled, unused, arrival counter, [4..20) 16 partial attempt
+ *   counters (mode 0 diagnostic: their sum is the number of attempts made so far; B / attempts = acceptance rate),
+ *   [20..36) arrival sub-counters}. */
 int ultr_batch_assemble(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
                         int click_model, const double* exam, int n_exam, const double* click_prob,
                         int n_click_prob, int mode, unsigned long long seed, unsigned int step,

@@ -270,22 +270,24 @@ def test_eval_step_and_direct_label_feed():
     assert list(merged) == ['mrr_3', 'mrr_5', 'mrr_10', 'ndcg_3', 'ndcg_5', 'ndcg_10']
 
 
-def test_python_rng_feed_is_bit_exact_with_the_reference_stream():
+@pytest.mark.parametrize('model_json', ['pbm_0.1_1.0_4_1.0.json', 'ubm_0.1_1_4_1.0.json', 'trust_bias.json'])
+def test_python_rng_feed_is_bit_exact_with_the_reference_stream(model_json):
     """device_rng=False: the batch and the post-call state of Python's `random` equal what the reference's
-    get_batch produces/leaves (click_simulation_feed.py:131-137; q2)."""
+    get_batch produces/leaves (click_simulation_feed.py:131-137; q2), for click models of every device kind."""
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
     import json
     data = SyntheticData(120, 10, 8, seed=17, pad_frac=0.2)
-    exp = settings('DLA', feed_hparams='click_model_json=%s,device_rng=False' % PBM)
+    path = os.path.join(os.path.dirname(PBM), model_json)
+    exp = settings('DLA', feed_hparams='click_model_json=%s,device_rng=False' % path)
     model, feed = make('DLA', data, exp, 200)
-    g = json.load(open(PBM))
+    g = json.load(open(path))
     random.seed(1234)
     feed_dict, info = feed.get_batch(data, check_validation=True)
     after = random.random()
     random.seed(1234)
     u = [random.random() for _ in range(200 * 11 * 8)]
     idxs, clicks, n_cand = O.get_batch_sequential(data.initial_list, data.labels, 10, 200, g['model_name'],
-                                                  g['click_prob'], g['exam_prob'], u, True)
+                                                  g['click_prob'], g['exam_prob'], u, True, g.get('extra'))
     assert [x[0] for x in info['rank_list_idxs']] == idxs
     assert np.array_equal(feed_dict[DEVICE_BATCH_KEY].labels.cpu().numpy().T, np.array(clicks, dtype=np.float32))
     assert after == u[n_cand * 11]  # exactly n_cand * (1 + L) draws were consumed

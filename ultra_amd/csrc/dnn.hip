@@ -103,7 +103,15 @@ static Layout make_layout(const UltrDnnDesc* d, long long M) {
   }
   for (int j = 0; j < L.H; ++j) {
     const long long tiles = cdiv(L.K[j], 64) * cdiv(L.N[j], 64);
-    long long want = cdiv(256, tiles);  // ~one workgroup per CU per layer
+    // Whole rounds of workgroups: at most one per CU (256) -- 24 tiles x 11 slabs = 264 workgroups would run a
+    // second round for 8 of them and take twice as long -- or, when every slab still spans 512 rows, three per CU
+    // (768): the GEMM streams its operands straight into registers, and three resident workgroups per CU hide
+    // that latency (K136 N512 at M = 40960: 178 us with 264 workgroups, 139 with 504, 106 with 768, 119 with 1008).
+    long long want = 256 / tiles > 1 ? 256 / tiles : 1;
+    {
+      const long long w3 = 768 / tiles > 1 ? 768 / tiles : 1;
+      if (M / w3 >= 512) want = w3;
+    }
     const long long max_split = cdiv(M, 64);
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;

@@ -66,6 +66,11 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
 
   const int lane = threadIdx.x & 63;
   const int b = bid * 4 + (threadIdx.x >> 6);
+  // diagnostic attempt count: the block's slots meet in LDS, and the blocks spread their sums over 16 counters --
+  // one atomic per slot on ONE address serialises in L2 at ~16 ns each, 64 us for a batch of 4096
+  __shared__ int s_attempts;
+  if (threadIdx.x == 0) s_attempts = 0;
+  __syncthreads();
   // A hipGraph replays frozen kernel arguments, so the per-step Philox counter lives in device memory.  One thread
   // per block reads it and hands it to the others through LDS; the bump needs no hand-off of data, only "every block
   // has read the counter": the block arrives right after its read (the increment is made to depend on the value
@@ -76,11 +81,19 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
     if (threadIdx.x == 0) {
       const unsigned int cur = __hip_atomic_load(step_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_cur = cur;
-      unsigned int* arrive = reinterpret_cast<unsigned int*>(&info[3]);
-      const unsigned int t = __hip_atomic_fetch_add(arrive, 1u + (cur & 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (unsigned)nb - 1) {
-        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // two levels (16 sub-counters, then info[3]): a thousand returning atomics on one address take 16 us
+      unsigned int* sub = reinterpret_cast<unsigned int*>(&info[20 + (bid & 15)]);
+      const unsigned int n_sub = ((unsigned)nb - (unsigned)(bid & 15) + 15u) / 16u;  // blocks that share this sub-counter
+      const unsigned int t = __hip_atomic_fetch_add(sub, 1u + (cur & 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == n_sub - 1) {
+        __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int* arrive = reinterpret_cast<unsigned int*>(&info[3]);
+        const unsigned int n_top = nb < 16 ? (unsigned)nb : 16u;
+        const unsigned int t2 = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t2 == n_top - 1) {
+          __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     __syncthreads();
@@ -155,10 +168,12 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
       out_clicks[(long long)pos * B + b] = cv;
       if (pos == 0) {
         out_list_idx[b] = i;
-        atomicAdd(&info[2], attempts);  // diagnostic: acceptance rate = B / total attempts
+        atomicAdd(&s_attempts, attempts);  // diagnostic: acceptance rate = B / total attempts
       }
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_attempts) atomicAdd(&info[4 + (bid & 15)], s_attempts);
 }
 
 

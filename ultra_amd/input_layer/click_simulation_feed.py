@@ -61,7 +61,7 @@ class ClickSimulationFeed(BaseInputFeed):
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
         if hasattr(model, 'step_ctr'):
             model.step_ctr = self.step_ctr  # regression-EM draws its Bernoulli uniforms on the same counter
-        self.info = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.info = torch.zeros(36, dtype=torch.int32, device=self.device)
         self._out = {}
         # prefetch: (data set, batch size, check_validation) the buffers were last filled / parked for
         self._prefetched = None
