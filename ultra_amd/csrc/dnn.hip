@@ -1722,7 +1722,7 @@ struct FinalizeArgs {
 };
 
 __device__ __forceinline__ void finalize_body(const FinalizeArgs& p, const int blk) {
-  __shared__ float red[8];
+  __shared__ float red[12];
   if (blk >= p.row_start[p.H]) {  // output layer: column sums of the [out_blocks][3K+4] partial rows
     __shared__ float s_col[4][64];
     const int K = p.Kout, j = p.H;
@@ -1763,47 +1763,78 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& p, const int b
   float* dW = p.grads + p.off_W[j] + (long long)k * ldn;
   const float gam = p.has_ln ? p.params[p.off_gamma[j] + k] : 1.f;
   const float bet = p.has_ln ? p.params[p.off_beta[j] + k] : 0.f;
-  float v[2] = {0.f, 0.f}, q[1] = {0.f};
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    // slabs are summed in a fixed order; 4 independent partial sums keep 8 loads in flight
+  // Slab sums in a fixed order with every load of a round in flight at once (up to 16 slabs x 2 streams): a thread
+  // that walks its slabs four at a time pays one L2 round trip per four slabs, and this launch sits at the end of the
+  // backward pass with nothing to hide behind.  Narrow layers (N <= 128, a power of two) put the idle threads to work:
+  // the block's 256 / N thread groups take alternate slabs and meet in LDS, again in fixed order.
+  __shared__ float s_comb[2][kThreads];
+  const float* __restrict__ gsl = p.gslab[j] + (long long)k * ldn;
+  const float* __restrict__ ssl = p.sslab[j];
+  const long long gstride = (long long)p.K[j] * ldn;
+  const int groups = (N <= 128 && (N & (N - 1)) == 0) ? (int)blockDim.x / N : 1;
+  auto slab_sums = [&](int n, int s0, int sstep, float* Gout, float* Sout) {
     float G4[4] = {0.f, 0.f, 0.f, 0.f}, S4[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* gp = p.gslab[j] + (long long)k * ldn + n;
-    const float* sp = p.sslab[j] + n;
-    const long long gstride = (long long)p.K[j] * ldn;
-    int s = 0;
-    for (; s + 4 <= ns; s += 4) {
+    for (int base = s0; base < ns; base += 16 * sstep) {
+      float g[16], sv[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        G4[q] += gp[(long long)(s + q) * gstride];
-        S4[q] += sp[(long long)(s + q) * ldn];
+      for (int u = 0; u < 16; ++u) {
+        const int sl = min(base + u * sstep, ns - 1);
+        g[u] = gsl[(long long)sl * gstride + n];
+        sv[u] = ssl[(long long)sl * ldn + n];
       }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (base + u * sstep < ns) {
+          G4[u & 3] += g[u];
+          S4[u & 3] += sv[u];
+        }
     }
-    for (; s < ns; ++s) {
-      G4[0] += gp[(long long)s * gstride];
-      S4[0] += sp[(long long)s * ldn];
-    }
-    const float G = (G4[0] + G4[1]) + (G4[2] + G4[3]), S = (S4[0] + S4[1]) + (S4[2] + S4[3]);
+    *Gout = (G4[0] + G4[1]) + (G4[2] + G4[3]);
+    *Sout = (S4[0] + S4[1]) + (S4[2] + S4[3]);
+  };
+  float v[3] = {0.f, 0.f, 0.f};  // sum_n W G, sum_n W S, sum of squares of what this block stores
+  auto emit = [&](int n, float G, float S) {
     const float dw = gam * G + bet * S;
     dW[n] = dw;
-    q[0] += dw * dw;
+    v[2] += dw * dw;
     const float wv = W[n];
     v[0] += wv * G;
     v[1] += wv * S;
     if (k == 0) {
       p.grads[p.off_b[j] + n] = S;
-      q[0] += S * S;
+      v[2] += S * S;
+    }
+  };
+  if (groups > 1) {
+    const int n = threadIdx.x & (N - 1), g = threadIdx.x / N;
+    float G, S;
+    slab_sums(n, g, groups, &G, &S);
+    s_comb[0][threadIdx.x] = G;
+    s_comb[1][threadIdx.x] = S;
+    __syncthreads();
+    if (g == 0) {
+      for (int o = 1; o < groups; ++o) {
+        G += s_comb[0][o * N + n];
+        S += s_comb[1][o * N + n];
+      }
+      emit(n, G, S);
+    }
+  } else {
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      float G, S;
+      slab_sums(n, 0, 1, &G, &S);
+      emit(n, G, S);
     }
   }
-  if (p.has_ln) {
-    block_sum<2>(v, red);
+  if (p.has_ln || p.sumsq) {
+    block_sum<3>(v, red);
     if (threadIdx.x == 0) {
-      p.grads[p.off_gamma[j] + k] = v[0];
-      p.grads[p.off_beta[j] + k] = v[1];
+      if (p.has_ln) {
+        p.grads[p.off_gamma[j] + k] = v[0];
+        p.grads[p.off_beta[j] + k] = v[1];
+      }
+      if (p.sumsq) p.sumsq[blk] = v[2] + (p.has_ln ? v[0] * v[0] + v[1] * v[1] : 0.f);
     }
-  }
-  if (p.sumsq) {
-    block_sum<1>(q, red);
-    if (threadIdx.x == 0) p.sumsq[blk] = q[0] + (p.has_ln ? v[0] * v[0] + v[1] * v[1] : 0.f);
   }
 }
 __global__ void __launch_bounds__(kThreads) finalize_kernel(FinalizeArgs p) { finalize_body(p, blockIdx.x); }
