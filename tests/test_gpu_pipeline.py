@@ -126,3 +126,46 @@ def test_dla_ndcg10_after_fixed_step_count_matches_reference():
     assert abs(after['ndcg_10'] - want['ndcg_10']) < 1e-4, (after['ndcg_10'], want['ndcg_10'])
     assert abs(after['ndcg_3'] - want['ndcg_3']) < 2e-4
 
+
+
+def test_main_train_validate_checkpoint_and_test(tmp_path, capsys):
+    """ultra_amd.main: the reference's own settings file layout (tests/test_settings/dnn.json: `ultra.*` class names,
+    objective_metric ndcg_10) driven through train() -- feed, steps, validation every steps_per_checkpoint steps, the
+    best-checkpoint rule (main.py:180-194) -- then test() from that checkpoint: merged summary and TREC rank lists."""
+    import json
+    from ultra_amd import main as M
+    exp = {
+        'train_input_feed': 'ultra.input_layer.ClickSimulationFeed', 'train_input_hparams': 'click_model_json=%s,seed=3' % PBM,
+        'valid_input_feed': 'ultra.input_layer.DirectLabelFeed', 'valid_input_hparams': '',
+        'test_input_feed': 'ultra.input_layer.DirectLabelFeed', 'test_input_hparams': '',
+        'ranking_model': 'ultra.ranking_model.DNN', 'ranking_model_hparams': 'hidden_layer_sizes=[64, 32]',
+        'learning_algorithm': 'ultra.learning_algorithm.DLA', 'learning_algorithm_hparams': '',
+        'metrics': ['mrr', 'ndcg'], 'metrics_topn': [3, 5, 10], 'objective_metric': 'ndcg_10', 'seed': 1}
+    flags = M.Flags(data_dir=os.path.join(GOLDEN, 'toy_ultra') + '/', model_dir=str(tmp_path / 'model'),
+                    output_dir=str(tmp_path / 'out') + '/', batch_size=32, steps_per_checkpoint=8, max_train_iteration=30,
+                    test_while_train=True)
+    history = M.train(json.loads(json.dumps(exp)), flags)
+    out = capsys.readouterr().out
+    assert [h['step'] for h in history] == [8, 16, 24, 32]          # stops at the first interval past max_train_iteration
+    assert 'Users can only see the top 9 documents' in out and 'global step 8 learning rate 0.0500' in out
+    assert all(np.isfinite(h['loss']) and set(h['valid']) >= {'ndcg_10', 'mrr_3'} and 'test' in h for h in history)
+    # a checkpoint is written exactly when validation ndcg_10 improves on the best so far
+    best, want_saved = None, []
+    for h in history:
+        better = best is None or best < h['valid']['ndcg_10']
+        want_saved.append(better)
+        best = h['valid']['ndcg_10'] if better else best
+    assert [h['saved'] is not None for h in history] == want_saved and want_saved[0]
+    last_saved = [h for h in history if h['saved']][-1]
+    assert os.path.exists(last_saved['saved'] + '.pt')
+    # test(): a forward-only model restored from that checkpoint reproduces the validation numbers of that interval on the
+    # test split the training loop evaluated, and writes one TREC line per (query, document)
+    flags.test_only = True
+    summary, scores = M.test(json.loads(json.dumps(exp)), flags)
+    assert 'Reading model parameters from' in capsys.readouterr().out
+    for tag, v in last_saved['test'].items():
+        assert abs(summary[tag] - v) < 1e-6, (tag, summary[tag], v)
+    lines = open(os.path.join(flags.output_dir, 'test.ranklist')).read().strip().split('\n')
+    from ultra_amd.utils import read_data
+    test_set = read_data(flags.data_dir, 'test')
+    assert len(scores) == len(test_set.initial_list) and len(lines) == sum(len(x) for x in test_set.initial_list)
