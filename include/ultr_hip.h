@@ -155,6 +155,26 @@ int ultr_batch_assemble_flush(void* stream);
 /* Drops a parked request without running it (its output buffers are about to go away); returns 1 if there was one. */
 int ultr_batch_assemble_cancel(void);
 
+/* ---- online simulation: DeterministicOnlineSimulationFeed.simulate_clicks_online
+ * (deterministic_online_simulation_feed.py:106-194) -----------------------------------------------
+ * docids / labels / scores [Lmax][B] position-major: the sampled lists in their initial order (pad doc id = n_rows,
+ * pad label 0), their true relevance labels, and the current model's scores for them.  Per list:
+ *   list_len = 1 + last position holding a real document (:131-137);
+ *   positions < list_len are re-ranked by score, descending, equal scores keeping their order (Python's stable
+ *   sorted(reverse=True), :156-161); out_docids / the labels follow that order, positions >= list_len stay (:163-183);
+ *   out_clicks: ranks < min(L, list_len) are sampled from the click model on the re-ranked labels (tables as for
+ *   ultr_click_sample; ULTR_CLICK_ORACLE copies the labels, :170-171), other ranks < list_len are 0 (:186-187);
+ *   check_validation: a list without a click is sampled again, at most max_rounds more times (:176-180).
+ * uniforms != NULL: [B][L] float64, one round (check_validation must be 0); NULL: Philox4x32-10, counter
+ *   (slot_base + b, round, block, step + *step_ctr), key = seed.  The caller advances *step_ctr (or step).
+ * out_perm (may be NULL) [Lmax][B]: the initial position of the document now at each rank.
+ * Limits: L <= ULTR_MAX_LIST, Lmax <= ULTR_MAX_SORT. */
+int ultr_online_rerank_click(const int* docids, const float* labels, const float* scores, int B, int Lmax, int L,
+                             int n_rows, int click_model, const double* exam, int n_exam, const double* click_prob,
+                             int n_click_prob, const double* uniforms, unsigned long long seed, unsigned int step,
+                             const unsigned int* step_ctr, unsigned int slot_base, int check_validation, int max_rounds,
+                             int* out_docids, float* out_clicks, int* out_perm, void* stream);
+
 /* ---- DNN scorer (DNN.py:48-96 via base_algorithm.py:104-134) ---------------------------- */
 /* Bytes of workspace ultr_dnn_forward/backward need for M rows (M = L*B). */
 long long ultr_dnn_workspace_bytes(const UltrDnnDesc* desc, long long M);

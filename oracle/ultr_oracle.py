@@ -205,6 +205,39 @@ def get_batch_slots(initial_list, labels, rank_list_size, batch_size, model_name
     return idxs, clicks, attempts
 
 
+def online_rerank_click(docids, labels, scores, n_rows, rank_list_size, model_name, click_prob, exam_prob,
+                        uniforms, extra=None, oracle_mode=False):
+    """deterministic_online_simulation_feed.py:129-187 for one batch, with the click draws supplied.
+
+    docids / labels / scores are list-major [B][Lmax]; ``uniforms[i]`` stands for the ``random.random()`` results of
+    list i's (single) sampleClicksForOneList call.  Returns (docids, clicks, order), list-major.
+    """
+    B, Lmax = len(docids), len(docids[0])
+    out_docids = [list(row) for row in docids]
+    out_clicks = [list(row) for row in labels]
+    orders = []
+    for i in range(B):
+        valid_idx = Lmax - 1                                                   # :131-137
+        while valid_idx > -1:
+            if docids[i][valid_idx] < n_rows:
+                break
+            valid_idx -= 1
+        list_len = valid_idx + 1
+        s = [scores[i][k] for k in range(list_len)]
+        rerank_list = sorted(range(len(s)), key=lambda k: s[k], reverse=True)  # :156-161 (stable)
+        new_label_list = [labels[i][rerank_list[j]] for j in range(list_len)]
+        if oracle_mode:
+            click_list = new_label_list[:rank_list_size]                       # :170-171
+        else:
+            click_list = sample_clicks_one_list(model_name, click_prob, exam_prob, new_label_list[:rank_list_size],
+                                                uniforms[i], extra)             # :173-174
+        for j in range(list_len):                                              # :182-187
+            out_docids[i][j] = docids[i][rerank_list[j]]
+            out_clicks[i][j] = click_list[j] if j < rank_list_size else 0
+        orders.append(rerank_list + list(range(list_len, Lmax)))
+    return out_docids, out_clicks, orders
+
+
 def propensity_for_one_list(ipw_list, click_list):
     """propensity_estimator.py:33-42 (getPropensityForOneList, clicked ranks only)."""
     return [(ipw_list[r] if r < len(ipw_list) else ipw_list[-1]) if click_list[r] > 0 else 0.0

@@ -701,3 +701,54 @@ def test_alternate_kernel_paths_in_a_fresh_process(env):
                         'dnn_forward_backward or dla_steps_match or naive_steps_match'],
                        cwd=root, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------
+# online simulation: re-rank by score + click model
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('model_file,B,Lmax,Ls', [('pbm_0.1_1.0_4_1.0.json', 200, 12, 10), ('cascade_0.1_1.0_4_1.0.json', 64, 9, 9),
+                                                  ('ubm_0.1_1_4_1.0.json', 100, 30, 10), ('trust_bias.json', 50, 300, 10),
+                                                  ('oracle', 40, 12, 5)])
+def test_online_rerank_click_kernel(L, model_file, B, Lmax, Ls):
+    """ultr_online_rerank_click against the reference's per-list loop (deterministic_online_simulation_feed.py:129-187):
+    list length from the last real document, stable descending sort with exact score ties, permuted doc ids, clicks on
+    the shown ranks from supplied uniforms, zeros beyond, padding untouched -- bit for bit."""
+    model = {'model_name': 'oracle', 'click_prob': [1.0], 'exam_prob': [1.0]} if model_file == 'oracle' else load_json(model_file)
+    rng = np.random.RandomState(B + Lmax)
+    n_rows = 5000
+    lens = rng.randint(0, Lmax + 1, size=B)
+    lens[:3] = [Lmax, 0, 1]
+    docids = np.full((B, Lmax), n_rows, dtype=np.int32)
+    labels = np.zeros((B, Lmax), dtype=np.float32)
+    for i in range(B):
+        docids[i, :lens[i]] = rng.choice(n_rows, size=lens[i], replace=False)
+        labels[i, :lens[i]] = rng.choice(5, size=lens[i])
+    scores = np.round(rng.normal(size=(B, Lmax)), 1).astype(np.float32)   # one decimal: plenty of exact ties
+    u = rng.random_sample((B, Ls)) * 0.7
+    kind, exam, n_exam, cp = _device_click_model(model, Ls)
+    out_d = torch.full((Lmax, B), -5, dtype=torch.int32, device='cuda')
+    out_c = torch.full((Lmax, B), -5.0, dtype=torch.float32, device='cuda')
+    out_p = torch.full((Lmax, B), -5, dtype=torch.int32, device='cuda')
+    L.check(L.lib().ultr_online_rerank_click(
+        L.ptr(dev(docids.T)), L.ptr(dev(labels.T)), L.ptr(dev(scores.T)), B, Lmax, Ls, n_rows, kind, L.ptr(exam), n_exam,
+        L.ptr(cp), cp.numel(), L.ptr(dev(u)), 0, 0, None, 0, 0, 100, L.ptr(out_d), L.ptr(out_c), L.ptr(out_p), stream(L)), 'online')
+    want_d, want_c, want_p = O.online_rerank_click(
+        docids.tolist(), labels.tolist(), scores.tolist(), n_rows, Ls, model['model_name'], model['click_prob'],
+        model['exam_prob'], u, model.get('extra'), oracle_mode=model_file == 'oracle')
+    assert np.array_equal(out_p.cpu().numpy().T, np.array(want_p))
+    assert np.array_equal(out_d.cpu().numpy().T, np.array(want_d))
+    assert np.array_equal(out_c.cpu().numpy().T, np.array(want_c, dtype=np.float32))
+    if model_file == 'oracle':
+        return
+    # Philox rounds with check_validation: every list that shows a document ends up with a click, in place
+    d_io, c_io = dev(docids.T).clone(), dev(labels.T).clone()
+    L.check(L.lib().ultr_online_rerank_click(
+        L.ptr(d_io), L.ptr(c_io), L.ptr(dev(scores.T)), B, Lmax, Ls, n_rows, kind, L.ptr(exam), n_exam, L.ptr(cp),
+        cp.numel(), None, 99, 4, None, 0, 1, 100, L.ptr(d_io), L.ptr(c_io), None, stream(L)), 'online')
+    assert torch.equal(d_io, out_d)
+    got = c_io.cpu().numpy().T
+    shown_relevant = np.array([(np.array(want_d[i][:Ls]) < n_rows).any() for i in range(B)])
+    assert (got[shown_relevant].sum(1) >= 1).all() and (got[~shown_relevant] == 0).all()
+    assert (got[:, Ls:] == 0).all() and set(np.unique(got)) <= {0.0, 1.0}
+    if model['model_name'] == 'cascade_model':
+        assert (got.sum(1) <= 1).all()

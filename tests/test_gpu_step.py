@@ -347,3 +347,71 @@ def test_prefetching_feed_yields_the_same_batches_and_steps():
     assert not torch.equal(b0[0][0], b0[1][0])  # and they are different batches
     assert torch.equal(d10, d11) and torch.equal(d20, d21) and not torch.equal(d10, d20)
     assert torch.equal(p0, p1) and torch.equal(q0, q1)
+
+
+def test_online_simulation_feed_python_stream_and_training():
+    """DeterministicOnlineSimulationFeed: (a) device_rng=False reproduces the reference's get_batch from the same
+    random.random() stream -- one index draw per slot, irrelevant lists dropped, lists re-ranked by the current model,
+    clicks re-sampled per list until one lands (deterministic_online_simulation_feed.py:106-270) -- and leaves the
+    stream where the reference would; (b) the default device stream trains a model through the usual step()."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY, DeviceBatch
+    from ultra_amd.input_layer import DeterministicOnlineSimulationFeed
+    from ultra_amd.input_layer.device_dataset import DeviceDataset
+    import json
+    Lmax, Ls, B = 14, 10, 96
+    data = SyntheticData(150, Lmax, 12, seed=31, pad_frac=0.3)
+    data.labels[::9] = 0.0                                   # some lists without any relevant document
+    exp = settings('DLA', Lmax=Lmax, cutoff=Ls)
+    model, _ = make('DLA', data, exp, B)
+    g = json.load(open(PBM))
+    feed = DeterministicOnlineSimulationFeed(model, B, 'click_model_json=%s,device_rng=False' % PBM, None)
+    random.seed(99)
+    feed_dict, info = feed.get_batch(data, check_validation=True)
+    after = random.random()
+    # the reference's loop on the same stream
+    random.seed(99)
+    picks = [int(random.random() * 150) for _ in range(B)]
+    assert info['rank_list_idxs'] == picks
+    kept = [i for i in picks if sum(0 if data.initial_list[i][x] < 0 else data.labels[i][x] for x in range(Lmax)) != 0]
+    assert 0 < len(kept) < B
+    n_rows = data.features.shape[0]
+    docids = np.where(data.initial_list[kept] < 0, n_rows, data.initial_list[kept])
+    labels = np.where(data.initial_list[kept] < 0, 0, data.labels[kept])
+    dd = DeviceDataset.of(data, model.device)
+    d_dev = torch.tensor(docids.T.copy(), dtype=torch.int32, device='cuda')
+    scores = model.ranking_model(Lmax, DeviceBatch(dd.table, dd.stats, dd.n_rows, d_dev, None)).cpu().numpy().T
+    want_d, want_c = docids.copy(), labels.astype(np.float32).copy()
+    for i in range(len(kept)):
+        n = int((docids[i] < n_rows).nonzero()[0].max()) + 1
+        order = sorted(range(n), key=lambda k: scores[i][k], reverse=True)
+        shown = [float(labels[i][order[j]]) for j in range(min(n, Ls))]
+        for _ in range(101):
+            clicks = O.sample_clicks_one_list(g['model_name'], g['click_prob'], g['exam_prob'], shown,
+                                              [random.random() for _ in shown])
+            if sum(clicks) > 0:
+                break
+        want_d[i, :n] = docids[i][order]
+        want_c[i, :n] = 0
+        want_c[i, :len(clicks)] = clicks
+    batch = feed_dict[DEVICE_BATCH_KEY]
+    assert batch.docids.shape == (Lmax, len(kept))
+    assert np.array_equal(batch.docids.cpu().numpy().T, want_d)
+    assert np.array_equal(batch.labels.cpu().numpy().T, want_c)
+    assert after == random.random()                          # the stream was left exactly where the reference leaves it
+    assert [list(x) for x in info['input_list']] == docids.tolist()
+    assert torch.equal(feed_dict[model.docid_inputs[3].name], batch.docids[3])
+    # (b) device stream: a few training steps, every fed list has a click among the shown ranks, the model moves
+    feed = DeterministicOnlineSimulationFeed(model, B, 'click_model_json=%s,seed=5' % PBM, None)
+    before = model.model.params.clone()
+    seen = []
+    for _ in range(3):
+        feed_dict, info = feed.get_batch(data, check_validation=True)
+        b = feed_dict[DEVICE_BATCH_KEY]
+        assert (b.labels[:Ls].sum(0) >= 1).all() and (b.labels[Ls:] == 0).all()
+        seen.append(b.labels.clone())
+        loss, _, _ = model.step(None, feed_dict, False)
+        assert np.isfinite(float(loss))
+    assert not torch.equal(before, model.model.params)
+    assert not torch.equal(seen[0][:, :8], seen[1][:, :8])
+    nb, _ = feed.get_next_batch(140, data, check_validation=False)
+    assert nb[DEVICE_BATCH_KEY].docids.shape == (Lmax, 10)

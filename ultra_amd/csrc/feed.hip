@@ -141,6 +141,111 @@ __global__ void __launch_bounds__(1024) assemble_sequential_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Online simulation (deterministic_online_simulation_feed.py:106-194): every list is re-ranked by the current
+// model's scores and the click model runs on the result.  One workgroup per list; the list lives in LDS.
+//   list_len = 1 + last position holding a real document (:131-137)
+//   order    = positions < list_len by score, descending, equal scores keep their order (Python's stable
+//              sorted(reverse=True), :156-161): rank(p) = #{q : s_q > s_p or (s_q == s_p and q < p)}
+//   docids / labels of positions < list_len are permuted (:163-167, 182-183), the rest stay
+//   clicks for ranks < min(L, list_len) on the re-ranked labels (:169-180), re-sampled while the list has no click
+//   (check_validation, at most max_rounds more rounds, :176-180); labels of ranks >= L become 0 (:186-187)
+// ---------------------------------------------------------------------------------------------
+struct OnlineArgs {
+  const int* docids; const float* labels; const float* scores;  // [Lmax][B]
+  int B, Lmax, L, n_rows, click_model;
+  ClickTables t;
+  const double* uniforms;  // [B][L] or NULL
+  unsigned long long seed; unsigned int step; const unsigned int* step_ctr; unsigned int slot_base;
+  int check_validation, max_rounds;
+  int* out_docids; float* out_clicks; int* out_perm;  // [Lmax][B]; out_perm may be NULL
+};
+
+__global__ void __launch_bounds__(256) online_rerank_click_kernel(OnlineArgs a) {
+  extern __shared__ float smem[];  // scores | labels | re-ranked labels | docids | order : 5 * Lmax words
+  const int Lmax = a.Lmax, B = a.B, tid = threadIdx.x;
+  float* s_score = smem;
+  float* s_lab = smem + Lmax;
+  float* s_rlab = smem + 2 * Lmax;
+  int* s_doc = reinterpret_cast<int*>(smem + 3 * Lmax);
+  int* s_order = reinterpret_cast<int*>(smem + 4 * Lmax);
+  __shared__ int s_len;
+  const int b = blockIdx.x;
+  if (tid == 0) s_len = 0;
+  __syncthreads();
+  for (int p = tid; p < Lmax; p += blockDim.x) {
+    const long long e = (long long)p * B + b;
+    const int d = a.docids[e];
+    s_doc[p] = d;
+    s_score[p] = a.scores[e];
+    s_lab[p] = a.labels[e];
+    if (d < a.n_rows) atomicMax(&s_len, p + 1);
+  }
+  __syncthreads();
+  const int len = s_len;
+  for (int p = tid; p < len; p += blockDim.x) {
+    const float sp = s_score[p];
+    int rank = 0;
+    for (int q = 0; q < len; ++q) {
+      const float sq = s_score[q];
+      rank += (sq > sp || (sq == sp && q < p)) ? 1 : 0;
+    }
+    s_order[rank] = p;
+  }
+  __syncthreads();
+  for (int r = tid; r < Lmax; r += blockDim.x) {
+    const int src = r < len ? s_order[r] : r;
+    const long long e = (long long)r * B + b;
+    a.out_docids[e] = s_doc[src];
+    s_rlab[r] = s_lab[src];
+    if (a.out_perm) a.out_perm[e] = src;
+    if (r >= a.L || r >= len) a.out_clicks[e] = r < len ? 0.f : s_lab[r];  // beyond the shown ranks / beyond the list
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  // wave 0: the click model on ranks < min(L, len), lane = rank
+  const int Lc = a.L < len ? a.L : len, lane = tid;
+  if (Lc == 0) return;
+  const bool live = lane < Lc;
+  const float lab = live ? s_rlab[lane] : 0.f;
+  unsigned long long mask = 0ull;
+  if (a.click_model == ULTR_CLICK_ORACLE) {
+    if (live) a.out_clicks[(long long)lane * B + b] = lab;  // oracle_mode: the labels themselves (:170-171)
+    return;
+  }
+  const unsigned int step = a.step + (a.step_ctr ? *a.step_ctr : 0u);
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32), slot = a.slot_base + (uint32_t)b;
+  const unsigned long long lmask = Lc >= 64 ? ~0ull : ((1ull << Lc) - 1ull);
+  const int rounds = a.uniforms ? 1 : 1 + (a.check_validation ? a.max_rounds : 0);
+  for (int round = 0; round < rounds; ++round) {
+    double u = 2.0;
+    if (live) {
+      if (a.uniforms) {
+        u = a.uniforms[(long long)b * a.L + lane];
+      } else {  // draw `lane` of the stream (slot, round, *, step): words (2 lane, 2 lane + 1) of its block sequence
+        const Philox4 bd = philox4x32_10(slot, (uint32_t)round, (uint32_t)(lane >> 1), step, k0, k1);
+        u = (lane & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+      }
+    }
+    bool c = false;
+    if (a.click_model == ULTR_CLICK_UBM) {
+      int last_click = -1;
+      for (int r = 0; r < Lc; ++r) {
+        const bool cr = live && lane == r && u < click_threshold(a.t, a.click_model, lane, lab, last_click);
+        if (__ballot(cr)) last_click = r;
+        c = c || cr;
+      }
+    } else {
+      c = live && u < click_threshold(a.t, a.click_model, lane, lab, -1);
+    }
+    mask = __ballot(c) & lmask;
+    if (a.click_model == ULTR_CLICK_CASCADE) mask &= (~mask + 1ull);  // only the first click counts
+    if (mask != 0ull || !a.check_validation) break;
+  }
+  if (live) a.out_clicks[(long long)lane * B + b] = ((mask >> lane) & 1ull) ? 1.f : 0.f;
+}
+
 }  // namespace ultr
 
 using namespace ultr;
@@ -296,4 +401,36 @@ extern "C" int ultr_batch_assemble_cancel(void) {
   const int was = g_pending_assemble.on ? 1 : 0;
   g_pending_assemble.on = false;
   return was;
+}
+
+extern "C" int ultr_online_rerank_click(const int* docids, const float* labels, const float* scores, int B, int Lmax,
+                                        int L, int n_rows, int click_model, const double* exam, int n_exam,
+                                        const double* click_prob, int n_click_prob, const double* uniforms,
+                                        unsigned long long seed, unsigned int step, const unsigned int* step_ctr,
+                                        unsigned int slot_base, int check_validation, int max_rounds, int* out_docids,
+                                        float* out_clicks, int* out_perm, void* stream) {
+  ULTR_REQUIRE(docids && labels && scores && out_docids && out_clicks && exam && click_prob, ULTR_EINVAL,
+               "ultr_online_rerank_click: null pointer");
+  ULTR_REQUIRE(B > 0 && Lmax > 0 && L > 0, ULTR_EINVAL, "ultr_online_rerank_click: bad sizes B=%d Lmax=%d L=%d", B, Lmax, L);
+  ULTR_REQUIRE(L <= Lmax, ULTR_EINVAL,
+               "Input ranklist length must be no less than the required list size, %d != %d.", Lmax, L);
+  ULTR_REQUIRE(L <= ULTR_MAX_LIST, ULTR_ELIMIT, "ultr_online_rerank_click: L=%d > %d", L, ULTR_MAX_LIST);
+  ULTR_REQUIRE(Lmax <= ULTR_MAX_SORT, ULTR_ELIMIT, "ultr_online_rerank_click: Lmax=%d > %d", Lmax, ULTR_MAX_SORT);
+  ULTR_REQUIRE(max_rounds >= 0, ULTR_EINVAL, "ultr_online_rerank_click: max_rounds=%d", max_rounds);
+  ULTR_REQUIRE(!(uniforms && check_validation), ULTR_EINVAL,
+               "ultr_online_rerank_click: supplied uniforms cover one round, check_validation needs the Philox stream");
+  int rc = click_model_ok("ultr_online_rerank_click", click_model, n_exam, n_click_prob);
+  if (rc) return rc;
+  OnlineArgs a{};
+  a.docids = docids; a.labels = labels; a.scores = scores; a.B = B; a.Lmax = Lmax; a.L = L; a.n_rows = n_rows;
+  a.click_model = click_model; a.t = ClickTables{exam, n_exam, click_prob, n_click_prob};
+  a.uniforms = uniforms; a.seed = seed; a.step = step; a.step_ctr = step_ctr; a.slot_base = slot_base;
+  a.check_validation = check_validation; a.max_rounds = max_rounds;
+  a.out_docids = out_docids; a.out_clicks = out_clicks; a.out_perm = out_perm;
+  {
+    ultr::ProfScope prof_("online_rerank_click_kernel", as_stream(stream));
+    hipLaunchKernelGGL(online_rerank_click_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * 5 * (size_t)Lmax,
+                       as_stream(stream), a);
+  }
+  return check_launch("online_rerank_click_kernel");
 }
