@@ -175,6 +175,19 @@ int ultr_online_rerank_click(const int* docids, const float* labels, const float
                              const unsigned int* step_ctr, unsigned int slot_base, int check_validation, int max_rounds,
                              int* out_docids, float* out_clicks, int* out_perm, void* stream);
 
+/* The same with the ranking SAMPLED from the scores (StochasticOnlineSimulationFeed.simulate_clicks_online,
+ * stochastic_online_simulation_feed.py:108-200): a Plackett-Luce draw, documents taken without replacement with
+ * p ~ exp(tau * score) (:140-158), realised as a descending sort of tau * score + Gumbel noise (the same distribution;
+ * np.random.choice's own stream is not reproduced, and documents whose probability underflows to 0 -- appended in
+ * index order by :150-157 -- simply sort last).  rank_uniforms [B][Lmax] float64 in (0,1) or NULL (Philox, counter
+ * (slot_base + b, 0xFFFFFFFF, block, step + *step_ctr)); noise = -log(-log(u)), keys in float64. */
+int ultr_online_sample_click(float tau, const double* rank_uniforms, const int* docids, const float* labels,
+                             const float* scores, int B, int Lmax, int L, int n_rows, int click_model,
+                             const double* exam, int n_exam, const double* click_prob, int n_click_prob,
+                             const double* uniforms, unsigned long long seed, unsigned int step,
+                             const unsigned int* step_ctr, unsigned int slot_base, int check_validation, int max_rounds,
+                             int* out_docids, float* out_clicks, int* out_perm, void* stream);
+
 /* ---- DNN scorer (DNN.py:48-96 via base_algorithm.py:104-134) ---------------------------- */
 /* Bytes of workspace ultr_dnn_forward/backward need for M rows (M = L*B). */
 long long ultr_dnn_workspace_bytes(const UltrDnnDesc* desc, long long M);

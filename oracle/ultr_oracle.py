@@ -206,7 +206,7 @@ def get_batch_slots(initial_list, labels, rank_list_size, batch_size, model_name
 
 
 def online_rerank_click(docids, labels, scores, n_rows, rank_list_size, model_name, click_prob, exam_prob,
-                        uniforms, extra=None, oracle_mode=False):
+                        uniforms, extra=None, oracle_mode=False, tau=None, rank_uniforms=None):
     """deterministic_online_simulation_feed.py:129-187 for one batch, with the click draws supplied.
 
     docids / labels / scores are list-major [B][Lmax]; ``uniforms[i]`` stands for the ``random.random()`` results of
@@ -224,6 +224,12 @@ def online_rerank_click(docids, labels, scores, n_rows, rank_list_size, model_na
             valid_idx -= 1
         list_len = valid_idx + 1
         s = [scores[i][k] for k in range(list_len)]
+        if tau is not None:
+            # stochastic_online_simulation_feed.py:140-158 draws the ranking from the Plackett-Luce model
+            # p ~ exp(tau * score) with np.random.choice; the same distribution as a sort of Gumbel-perturbed scores
+            # (the device formulation; the supplied uniforms stand for its noise draws)
+            s = [float(tau) * float(s[k]) - math.log(-math.log(max(float(rank_uniforms[i][k]), 2.0 ** -60)))
+                 for k in range(list_len)]
         rerank_list = sorted(range(len(s)), key=lambda k: s[k], reverse=True)  # :156-161 (stable)
         new_label_list = [labels[i][rerank_list[j]] for j in range(list_len)]
         if oracle_mode:

@@ -752,3 +752,51 @@ def test_online_rerank_click_kernel(L, model_file, B, Lmax, Ls):
     assert (got[:, Ls:] == 0).all() and set(np.unique(got)) <= {0.0, 1.0}
     if model['model_name'] == 'cascade_model':
         assert (got.sum(1) <= 1).all()
+
+
+def test_online_sample_click_kernel_plackett_luce(L):
+    """ultr_online_sample_click: with supplied noise uniforms the ranking equals the oracle's sort of Gumbel-perturbed
+    scores; with the Philox stream the first rank follows the Plackett-Luce law p ~ exp(tau * score)
+    (stochastic_online_simulation_feed.py:140-158) and two steps give different rankings."""
+    model = load_json('pbm_0.1_1.0_4_1.0.json')
+    rng = np.random.RandomState(3)
+    B, Lmax, Ls, n_rows, tau = 300, 12, 10, 1000, 2.0
+    lens = rng.randint(1, Lmax + 1, size=B)
+    docids = np.full((B, Lmax), n_rows, dtype=np.int32)
+    labels = np.zeros((B, Lmax), dtype=np.float32)
+    for i in range(B):
+        docids[i, :lens[i]] = rng.choice(n_rows, size=lens[i], replace=False)
+        labels[i, :lens[i]] = rng.choice(5, size=lens[i])
+    scores = rng.normal(size=(B, Lmax)).astype(np.float32)
+    u, ur = rng.random_sample((B, Ls)), rng.random_sample((B, Lmax))
+    kind, exam, n_exam, cp = _device_click_model(model, Ls)
+    out = [torch.empty((Lmax, B), dtype=t, device='cuda') for t in (torch.int32, torch.float32, torch.int32)]
+    common = lambda uu: (L.ptr(dev(docids.T)), L.ptr(dev(labels.T)), L.ptr(dev(scores.T)), B, Lmax, Ls, n_rows, kind,  # noqa: E731
+                         L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), uu)
+    L.check(L.lib().ultr_online_sample_click(tau, L.ptr(dev(ur)), *common(L.ptr(dev(u))), 0, 0, None, 0, 0, 100,
+                                             L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), stream(L)), 'online')
+    want_d, want_c, want_p = O.online_rerank_click(
+        docids.tolist(), labels.tolist(), scores.tolist(), n_rows, Ls, model['model_name'], model['click_prob'],
+        model['exam_prob'], u, tau=tau, rank_uniforms=ur)
+    assert np.array_equal(out[2].cpu().numpy().T, np.array(want_p))
+    assert np.array_equal(out[0].cpu().numpy().T, np.array(want_d))
+    assert np.array_equal(out[1].cpu().numpy().T, np.array(want_c, dtype=np.float32))
+    # Philox noise: one list replicated 20000 times, the document ranked first follows softmax(tau * score)
+    n, s4 = 20000, np.array([0.3, -0.2, 0.9, 0.0], dtype=np.float32)
+    d4 = np.tile(np.array([[5, 6, 7, 8, n_rows, n_rows]], dtype=np.int32), (n, 1))
+    sc = np.tile(np.concatenate([s4, [9.0, 9.0]]).astype(np.float32), (n, 1))    # pads score high and must stay put
+    o2 = [torch.empty((6, n), dtype=t, device='cuda') for t in (torch.int32, torch.float32, torch.int32)]
+    firsts = []
+    for step in (1, 2):
+        L.check(L.lib().ultr_online_sample_click(
+            tau, None, L.ptr(dev(d4.T)), L.ptr(dev(np.zeros((6, n), np.float32))), L.ptr(dev(sc.T)), n, 6, 4, n_rows, kind,
+            L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), None, 77, step, None, 0, 0, 100, L.ptr(o2[0]), L.ptr(o2[1]),
+            L.ptr(o2[2]), stream(L)), 'online')
+        perm = o2[2].cpu().numpy().T
+        assert (np.sort(perm[:, :4], axis=1) == np.arange(4)).all() and (perm[:, 4:] == [4, 5]).all()
+        firsts.append(perm[:, 0].copy())
+    p = np.exp(tau * s4.astype(np.float64))
+    p /= p.sum()
+    freq = np.bincount(firsts[0], minlength=4) / n
+    assert np.abs(freq - p).max() < 4 * np.sqrt(0.25 / n), (freq, p)
+    assert (firsts[0] != firsts[1]).mean() > 0.3

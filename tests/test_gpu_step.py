@@ -415,3 +415,17 @@ def test_online_simulation_feed_python_stream_and_training():
     assert not torch.equal(seen[0][:, :8], seen[1][:, :8])
     nb, _ = feed.get_next_batch(140, data, check_validation=False)
     assert nb[DEVICE_BATCH_KEY].docids.shape == (Lmax, 10)
+    # the stochastic feed: same contract, the ranking is a Plackett-Luce draw (tau scales the scores)
+    from ultra_amd.input_layer import StochasticOnlineSimulationFeed
+    sfeed = StochasticOnlineSimulationFeed(model, B, 'click_model_json=%s,tau=0.5,seed=5' % PBM, None)
+    random.seed(4)
+    fa, ia = sfeed.get_batch(data, check_validation=True)
+    da = fa[DEVICE_BATCH_KEY].docids.clone()
+    random.seed(4)
+    fb, ib = sfeed.get_batch(data, check_validation=True)                   # same lists, next draw of the rankings
+    db = fb[DEVICE_BATCH_KEY].docids
+    assert ia['rank_list_idxs'] == ib['rank_list_idxs'] and not torch.equal(da, db)
+    assert torch.equal(da.sort(dim=0).values, db.sort(dim=0).values)        # the same documents per list
+    assert (fb[DEVICE_BATCH_KEY].labels[:Ls].sum(0) >= 1).all()
+    loss, _, _ = model.step(None, fb, False)
+    assert np.isfinite(float(loss))

@@ -69,6 +69,8 @@ SIGNATURES = {
     'ultr_batch_assemble_cancel': (_I, []),
     'ultr_online_rerank_click': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _U, _I, _I, _P, _P, _P,
                                       _P]),
+    'ultr_online_sample_click': (_I, [_F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _ULL, _U, _P, _U, _I, _I, _P,
+                                      _P, _P, _P]),
     'ultr_dnn_workspace_bytes': (_LL, [_DESC, _LL]),
     'ultr_dnn_forward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P]),
     'ultr_dnn_backward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P, _P]),

@@ -157,19 +157,21 @@ struct OnlineArgs {
   int B, Lmax, L, n_rows, click_model;
   ClickTables t;
   const double* uniforms;  // [B][L] or NULL
+  int stochastic; float tau; const double* rank_uniforms;  // Plackett-Luce ranking (stochastic feed): [B][Lmax] or NULL
   unsigned long long seed; unsigned int step; const unsigned int* step_ctr; unsigned int slot_base;
   int check_validation, max_rounds;
   int* out_docids; float* out_clicks; int* out_perm;  // [Lmax][B]; out_perm may be NULL
 };
 
 __global__ void __launch_bounds__(256) online_rerank_click_kernel(OnlineArgs a) {
-  extern __shared__ float smem[];  // scores | labels | re-ranked labels | docids | order : 5 * Lmax words
+  extern __shared__ double smem_d[];  // sort keys (double) | labels | re-ranked labels | docids | order
   const int Lmax = a.Lmax, B = a.B, tid = threadIdx.x;
-  float* s_score = smem;
-  float* s_lab = smem + Lmax;
-  float* s_rlab = smem + 2 * Lmax;
-  int* s_doc = reinterpret_cast<int*>(smem + 3 * Lmax);
-  int* s_order = reinterpret_cast<int*>(smem + 4 * Lmax);
+  double* s_score = smem_d;
+  float* smem = reinterpret_cast<float*>(smem_d + Lmax);
+  float* s_lab = smem;
+  float* s_rlab = smem + Lmax;
+  int* s_doc = reinterpret_cast<int*>(smem + 2 * Lmax);
+  int* s_order = reinterpret_cast<int*>(smem + 3 * Lmax);
   __shared__ int s_len;
   const int b = blockIdx.x;
   if (tid == 0) s_len = 0;
@@ -178,17 +180,34 @@ __global__ void __launch_bounds__(256) online_rerank_click_kernel(OnlineArgs a) 
     const long long e = (long long)p * B + b;
     const int d = a.docids[e];
     s_doc[p] = d;
-    s_score[p] = a.scores[e];
+    double key = (double)a.scores[e];
+    if (a.stochastic) {
+      // Plackett-Luce sample of the ranking (stochastic_online_simulation_feed.py:140-158: documents drawn without
+      // replacement with p ~ exp(tau * score)) as a sort: Gumbel noise on tau * score, descending.  Same
+      // distribution; np.random.choice's own stream is not reproduced.
+      double u;
+      if (a.rank_uniforms) {
+        u = a.rank_uniforms[(long long)b * Lmax + p];
+      } else {
+        const unsigned int stp = a.step + (a.step_ctr ? *a.step_ctr : 0u);
+        const Philox4 bd = philox4x32_10(a.slot_base + (uint32_t)b, 0xFFFFFFFFu, (uint32_t)(p >> 1), stp,
+                                         (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        u = (p & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+      }
+      u = u > 8.673617379884035e-19 ? u : 8.673617379884035e-19;  // 2^-60: keeps the noise finite
+      key = (double)a.tau * key - log(-log(u));
+    }
+    s_score[p] = key;
     s_lab[p] = a.labels[e];
     if (d < a.n_rows) atomicMax(&s_len, p + 1);
   }
   __syncthreads();
   const int len = s_len;
   for (int p = tid; p < len; p += blockDim.x) {
-    const float sp = s_score[p];
+    const double sp = s_score[p];
     int rank = 0;
     for (int q = 0; q < len; ++q) {
-      const float sq = s_score[q];
+      const double sq = s_score[q];
       rank += (sq > sp || (sq == sp && q < p)) ? 1 : 0;
     }
     s_order[rank] = p;
@@ -403,7 +422,8 @@ extern "C" int ultr_batch_assemble_cancel(void) {
   return was;
 }
 
-extern "C" int ultr_online_rerank_click(const int* docids, const float* labels, const float* scores, int B, int Lmax,
+static int online_common(int stochastic, float tau, const double* rank_uniforms,
+                         const int* docids, const float* labels, const float* scores, int B, int Lmax,
                                         int L, int n_rows, int click_model, const double* exam, int n_exam,
                                         const double* click_prob, int n_click_prob, const double* uniforms,
                                         unsigned long long seed, unsigned int step, const unsigned int* step_ctr,
@@ -427,10 +447,33 @@ extern "C" int ultr_online_rerank_click(const int* docids, const float* labels, 
   a.uniforms = uniforms; a.seed = seed; a.step = step; a.step_ctr = step_ctr; a.slot_base = slot_base;
   a.check_validation = check_validation; a.max_rounds = max_rounds;
   a.out_docids = out_docids; a.out_clicks = out_clicks; a.out_perm = out_perm;
+  a.stochastic = stochastic; a.tau = tau; a.rank_uniforms = rank_uniforms;
   {
     ultr::ProfScope prof_("online_rerank_click_kernel", as_stream(stream));
-    hipLaunchKernelGGL(online_rerank_click_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * 5 * (size_t)Lmax,
-                       as_stream(stream), a);
+    hipLaunchKernelGGL(online_rerank_click_kernel, dim3((unsigned)B), dim3(256),
+                       (sizeof(double) + 4 * sizeof(float)) * (size_t)Lmax, as_stream(stream), a);
   }
   return check_launch("online_rerank_click_kernel");
+}
+
+extern "C" int ultr_online_rerank_click(const int* docids, const float* labels, const float* scores, int B, int Lmax,
+                                        int L, int n_rows, int click_model, const double* exam, int n_exam,
+                                        const double* click_prob, int n_click_prob, const double* uniforms,
+                                        unsigned long long seed, unsigned int step, const unsigned int* step_ctr,
+                                        unsigned int slot_base, int check_validation, int max_rounds, int* out_docids,
+                                        float* out_clicks, int* out_perm, void* stream) {
+  return online_common(0, 0.f, nullptr, docids, labels, scores, B, Lmax, L, n_rows, click_model, exam, n_exam, click_prob,
+                       n_click_prob, uniforms, seed, step, step_ctr, slot_base, check_validation, max_rounds, out_docids,
+                       out_clicks, out_perm, stream);
+}
+
+extern "C" int ultr_online_sample_click(float tau, const double* rank_uniforms, const int* docids, const float* labels,
+                                        const float* scores, int B, int Lmax, int L, int n_rows, int click_model,
+                                        const double* exam, int n_exam, const double* click_prob, int n_click_prob,
+                                        const double* uniforms, unsigned long long seed, unsigned int step,
+                                        const unsigned int* step_ctr, unsigned int slot_base, int check_validation,
+                                        int max_rounds, int* out_docids, float* out_clicks, int* out_perm, void* stream) {
+  return online_common(1, tau, rank_uniforms, docids, labels, scores, B, Lmax, L, n_rows, click_model, exam, n_exam,
+                       click_prob, n_click_prob, uniforms, seed, step, step_ctr, slot_base, check_validation, max_rounds,
+                       out_docids, out_clicks, out_perm, stream);
 }

@@ -31,15 +31,21 @@ from .device_dataset import DeviceDataset, LazyLists
 
 
 class DeterministicOnlineSimulationFeed(BaseInputFeed):
-    def __init__(self, model, batch_size, hparam_str, session=None):
-        self.hparams = hp.HParams(
+    BANNER = 'Create online deterministic simluation feed'
+    STOCHASTIC = False
+
+    def _default_hparams(self):
+        return hp.HParams(
             click_model_json='./example/ClickModel/pbm_0.1_1.0_4_1.0.json',
             oracle_mode=False,               # feed relevance labels instead of simulated clicks
             dynamic_bias_eta_change=0.0,     # eta increment for dynamic bias severity, 0 = off
             dynamic_bias_step_interval=1000,
             device_rng=True,                 # (new) False: click draws from Python's random stream, bit-exact
             seed=0)                          # (new) Philox key of the device stream
-        print('Create online deterministic simluation feed')
+
+    def __init__(self, model, batch_size, hparam_str, session=None):
+        self.hparams = self._default_hparams()
+        print(self.BANNER)
         print(hparam_str)
         self.hparams.parse(hparam_str)
         with open(self.hparams.click_model_json) as fin:
@@ -111,12 +117,15 @@ class DeterministicOnlineSimulationFeed(BaseInputFeed):
         python_stream = not self.hparams.device_rng and not self.hparams.oracle_mode
         # compatibility mode: the kernel only re-ranks (oracle mode copies the re-ranked labels), clicks follow on the host
         kind = _lib.CLICK_ORACLE if python_stream else self.kind
-        _lib.check(_lib.lib().ultr_online_rerank_click(
-            _lib.ptr(docids), _lib.ptr(labels), _lib.ptr(scores), B, Lmax, self.rank_list_size, dd.n_rows, kind,
-            _lib.ptr(self.exam), self.n_exam, _lib.ptr(self.click_prob), self.click_prob.numel(), None,
-            int(self.hparams.seed) & 0xFFFFFFFFFFFFFFFF, self.draw_step, None, parallel.slot_base(self.rank, B),
-            1 if check_validation else 0, self.MAX_SAMPLE_ROUND_NUM, _lib.ptr(new_docids), _lib.ptr(clicks), None,
-            _lib.current_stream()), 'ultr_online_rerank_click')
+        args = (_lib.ptr(docids), _lib.ptr(labels), _lib.ptr(scores), B, Lmax, self.rank_list_size, dd.n_rows, kind,
+                _lib.ptr(self.exam), self.n_exam, _lib.ptr(self.click_prob), self.click_prob.numel(), None,
+                int(self.hparams.seed) & 0xFFFFFFFFFFFFFFFF, self.draw_step, None, parallel.slot_base(self.rank, B),
+                1 if check_validation else 0, self.MAX_SAMPLE_ROUND_NUM, _lib.ptr(new_docids), _lib.ptr(clicks), None,
+                _lib.current_stream())
+        if self.STOCHASTIC:  # the ranking itself is a Plackett-Luce draw from the scores
+            _lib.check(_lib.lib().ultr_online_sample_click(float(self.hparams.tau), None, *args), 'ultr_online_sample_click')
+        else:
+            _lib.check(_lib.lib().ultr_online_rerank_click(*args), 'ultr_online_rerank_click')
         self.draw_step += 1
         if python_stream:
             L = self.rank_list_size
