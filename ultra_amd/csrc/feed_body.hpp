@@ -112,6 +112,15 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
     int i = 0, doc = -1, attempts = 0, gsel = 0;
     float lab = 0.f;
     unsigned long long mask = 0ull;
+    // PBM / cascade: this lane's examination probability and the (short) click-probability table are requested
+    // before the first attempt, so that the threshold needs no memory access once the label has arrived
+    const bool tables_in_regs = (click_model == ULTR_CLICK_PBM || click_model == ULTR_CLICK_CASCADE) && t.n_cp <= 8;
+    double exam_r = 0.0, cpv[8];
+    if (tables_in_regs) {
+      exam_r = t.exam[pos < t.n_exam ? pos : t.n_exam - 1];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cpv[q] = t.click_prob[q < t.n_cp ? q : t.n_cp - 1];
+    }
     for (int a0 = 0; a0 < max_attempts; a0 += G) {
       const int a = a0 + ai;
       // draw 0 (words 0,1 of block 0) picks the list: int(random.random() * length) (:132)
@@ -124,15 +133,27 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
       double u = 2.0;
       const bool live = pos < L && a < max_attempts;
       if (live) {
+        // both rows of the candidate are requested at once: a label load that waits for the doc id to turn out
+        // non-negative costs the wave a second memory round trip per attempt
         doc = initial_list[(long long)i * Lmax + pos];
-        lab = doc < 0 ? 0.f : labels[(long long)i * Lmax + pos];  // :80-82
+        const float lab_raw = labels[(long long)i * Lmax + pos];
+        lab = doc < 0 ? 0.f : lab_raw;  // :80-82
         if (click_model == ULTR_CLICK_ORACLE) {
           c = lab != 0.f;
         } else {
           const int d = 1 + pos;  // draws 1..L are the click draws (:87)
           const Philox4 bd = philox4x32_10(slot, (uint32_t)a, (uint32_t)(d >> 1), step, k0, k1);
           u = (d & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
-          if (click_model != ULTR_CLICK_UBM) c = u < click_threshold(t, click_model, pos, lab, -1);
+          if (tables_in_regs) {
+            int rel = lab > 0.f ? (int)lab : 0;     // click_threshold()'s rule: int() truncation, clamp to the table
+            rel = rel < t.n_cp ? rel : t.n_cp - 1;
+            double cp = cpv[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) cp = rel == q ? cpv[q] : cp;
+            c = u < exam_r * cp;
+          } else if (click_model != ULTR_CLICK_UBM) {
+            c = u < click_threshold(t, click_model, pos, lab, -1);
+          }
         }
       }
       if (click_model == ULTR_CLICK_UBM) {
