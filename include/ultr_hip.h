@@ -260,6 +260,19 @@ int ultr_loss_dla_deferred(const float* scores, const float* clicks, int B, int 
                            int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
                            float* prop_grads, float* list_weights, float* stats, float* ws, void* stream);
 int ultr_loss_flush(void* stream);
+/* The same for the IPW / naive loss (ultr_loss_ipw_fwdbwd: pw must be ready when the backward pass runs), the pairwise
+ * debiasing loss (ultr_loss_pd_fwdbwd) and the regression-EM loss (ultr_loss_rem_fwdbwd: its d_score is elementwise, sigmoid(score + b) - Bernoulli label, so the
+ * backward workgroups draw the label of each of their rows themselves, from the same Philox counter or the same
+ * supplied uniforms).  At most one request is parked per host thread; parking a second one launches the first. */
+int ultr_loss_ipw_deferred(const float* scores, const float* clicks, const float* pw, int B, int L, int loss_func,
+                           float* d_scores, float* stats, float* list_weights, float* ws, void* stream);
+int ultr_loss_pd_deferred(const float* scores, const float* clicks, int B, int L, const float* t_plus,
+                          const float* t_minus, float* d_scores, float* stats, float* ws, void* stream);
+int ultr_loss_rem_deferred(const float* scores, const float* clicks, int B, int L, const float* propensity,
+                           const float* sigmoid_prob_b, const float* uniforms, unsigned long long seed,
+                           unsigned int step, const unsigned int* step_ctr, unsigned int slot_base,
+                           float* d_scores, float* ranker_labels, float* list_weights,
+                           float* stats, float* d_bias, float* ws, void* stream);
 
 /* Regression-EM (regression_EM.py:116-176).  propensity [L] is the EM state (read, pre-update
  * value used for loss and gradient, q16).  uniforms [L][B] fp32 or NULL (Philox(seed, step)).

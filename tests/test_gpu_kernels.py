@@ -665,6 +665,54 @@ def test_dla_loss_rides_with_backward(L, F, hidden, B, Ls, loss_func, prob, maxw
             assert np.array_equal(a, b), (mode, name, np.abs(a - b).max())
 
 
+@pytest.mark.parametrize('kind', ['ipw', 'ipw_sigmoid', 'rem_uniforms', 'rem_philox', 'pd'])
+@pytest.mark.parametrize('F,hidden,B,Ls', [(136, [512, 256, 128], 256, 10), (46, [64, 32], 77, 16), (136, [], 40, 10)])
+def test_ipw_and_rem_losses_ride_with_backward(L, kind, F, hidden, B, Ls):
+    """ultr_loss_ipw_deferred / ultr_loss_rem_deferred against a loss launch of its own followed by the same backward
+    pass: statistics, d_scores, list weights, (REM) the bias gradient and ranker labels, and the parameter gradient,
+    bit for bit."""
+    model, ps, data, table, stats, n_rows, docids, d_lb, rng = _dnn_case(L, F, hidden, 'elu', 'layer', B, Ls, seed=F + B)
+    scores = model.forward_lists(table, stats, n_rows, d_lb)
+    clicks = dev(_scores_clicks(rng, B, Ls)[1].T, torch.float32)
+    pw = dev(rng.uniform(0.5, 3.0, size=(Ls, B)) * (clicks.cpu().numpy() > 0), torch.float32)
+    prop = dev(rng.uniform(0.2, 0.95, size=Ls), torch.float32)
+    bias = dev([0.3], torch.float32)
+    u = dev(rng.uniform(size=(Ls, B)), torch.float32)
+    tplus = dev(rng.uniform(0.8, 2.0, size=Ls), torch.float32)
+    lib = L.lib()
+
+    def run(ride):
+        d = torch.full((Ls, B), 3.0, dtype=torch.float32, device='cuda')
+        lw = torch.zeros(B, dtype=torch.float32, device='cuda')
+        st = torch.zeros(8 + 4 * Ls + Ls * Ls, dtype=torch.float32, device='cuda')
+        ws = _loss_ws(L, B, Ls)
+        grads = torch.full((model.n_total,), 7.0, dtype=torch.float32, device='cuda')
+        ylab = torch.zeros((Ls, B), dtype=torch.float32, device='cuda')
+        dbias = torch.zeros(1, dtype=torch.float32, device='cuda')
+        for _ in range(2):
+            if kind.startswith('ipw'):
+                fn = lib.ultr_loss_ipw_deferred if ride else lib.ultr_loss_ipw_fwdbwd
+                L.check(fn(L.ptr(scores), L.ptr(clicks), L.ptr(pw), B, Ls, 1 if kind == 'ipw_sigmoid' else 0, L.ptr(d),
+                           L.ptr(st), L.ptr(lw), L.ptr(ws), stream(L)), 'ipw')
+            elif kind == 'pd':
+                fn = lib.ultr_loss_pd_deferred if ride else lib.ultr_loss_pd_fwdbwd
+                L.check(fn(L.ptr(scores), L.ptr(clicks), B, Ls, L.ptr(tplus), L.ptr(prop), L.ptr(d), L.ptr(st), L.ptr(ws),
+                           stream(L)), 'pd')
+            else:
+                fn = lib.ultr_loss_rem_deferred if ride else lib.ultr_loss_rem_fwdbwd
+                L.check(fn(L.ptr(scores), L.ptr(clicks), B, Ls, L.ptr(prop), L.ptr(bias),
+                           L.ptr(u) if kind == 'rem_uniforms' else None, 0x5EED, 9, None, 1000, L.ptr(d), L.ptr(ylab),
+                           L.ptr(lw), L.ptr(st), L.ptr(dbias), L.ptr(ws), stream(L)), 'rem')
+            model.backward(d, grads)
+        L.check(lib.ultr_loss_flush(stream(L)), 'flush')
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (d, lw, st, grads, ylab, dbias)]
+    want, got = run(False), run(True)
+    assert np.abs(want[0] - 3.0).min() > 0 and np.abs(want[3][:model.desc.n_params]).max() > 0
+    for a, b, name in zip(got, want, ('d_scores', 'list_weights', 'stats', 'grads', 'ranker_labels', 'd_bias')):
+        assert np.array_equal(a, b), (kind, name, np.abs(a - b).max())
+
+
 def test_dnn_build_reference_api(L):
     from ultra_amd.ranking_model import DNN
     rng = np.random.RandomState(0)

@@ -977,7 +977,10 @@ struct BwdOutArgs {
   // are the loss kernel's own -- statistics, tower gradient, list weights, d_scores for whoever reads them later --
   // and the backward workgroups evaluate the d_score of each of their rows themselves (dla_lane) instead of
   // waiting for a loss launch to have written it: one launch less in the chain of dependent kernels.
-  DlaArgs dla; int dla_blocks, dla_pad;
+  // The same for the IPW / naive loss (per-element weights) and the regression-EM loss (elementwise): `ride` names the kind.
+  int ride;
+  DlaArgs dla; IpwArgs ipw; RemArgs rem; PdArgs pd;
+  int dla_blocks, dla_pad;
 };
 
 // generic fallback for very wide inputs (no hidden layer and more than 1024 features): LDS accumulators
@@ -1052,23 +1055,41 @@ __global__ void __launch_bounds__(kThreads) bwd_out_wide_kernel(BwdOutArgs p) {
 // One wave per row, four rows in flight per wave (all their loads are issued before the first use); lane l
 // owns columns k = l + 64 q and keeps the parameter-gradient sums of its columns in registers across the
 // wave's rows.  The four waves of a workgroup meet in LDS and write one partial row; finalize adds the rows.
-template <int KQ, bool DLA>
+template <int KQ, int RIDE>
 __global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
   extern __shared__ float smem[];  // [4 waves][3K+1]
-  if (DLA && (int)blockIdx.x < p.dla_pad) {
+  constexpr bool DLA = RIDE == ULTR_RIDE_DLA;
+  if (RIDE != ULTR_RIDE_NONE && (int)blockIdx.x < p.dla_pad) {
     __shared__ float s_acc[kMaxStat];
     __shared__ float s_part[4 * kMaxStat];
     __shared__ float s_tower[4 * 16];
-    if ((int)blockIdx.x < p.dla_blocks) dla_loss_small_body(p.dla, blockIdx.x, p.dla_blocks, s_acc, s_part, s_tower);
+    if ((int)blockIdx.x < p.dla_blocks) {
+      if (RIDE == ULTR_RIDE_DLA) dla_loss_small_body(p.dla, blockIdx.x, p.dla_blocks, s_acc, s_part, s_tower);
+      if (RIDE == ULTR_RIDE_IPW) ipw_loss_small_body(p.ipw, blockIdx.x, p.dla_blocks, s_acc, s_part);
+      if (RIDE == ULTR_RIDE_REM) rem_loss_small_body(p.rem, blockIdx.x, p.dla_blocks, s_acc, s_part);
+      if (RIDE == ULTR_RIDE_PD) pd_loss_small_body(p.pd, blockIdx.x, p.dla_blocks, s_acc, s_part, s_tower);
+    }
     return;
   }
-  const unsigned int bid = blockIdx.x - (DLA ? p.dla_pad : 0), nbid = gridDim.x - (DLA ? p.dla_pad : 0);
+  const unsigned int bid = blockIdx.x - (RIDE != ULTR_RIDE_NONE ? p.dla_pad : 0);
+  const unsigned int nbid = gridDim.x - (RIDE != ULTR_RIDE_NONE ? p.dla_pad : 0);
   const int K = p.f.K;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (long long i = (long long)bid * kThreads + threadIdx.x; i < p.zero_n4; i += (long long)nbid * kThreads)
     reinterpret_cast<float4*>(p.zero)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   float tower_pw = 0.f;  // DLA: inverse propensity weight of rank lane & 15
   if (DLA) tower_pw = dla_tower(p.dla.prop_params, p.dla.L, lane & 15, p.dla.prob_kind, p.dla.max_pw).pw;
+  float pd_tp = 1.f, pd_tm = 1.f;  // PD: t+ / t- of rank lane & 15
+  if (RIDE == ULTR_RIDE_PD) {
+    pd_tp = (lane & 15) < p.pd.L ? p.pd.t_plus[lane & 15] : 1.f;
+    pd_tm = (lane & 15) < p.pd.L ? p.pd.t_minus[lane & 15] : 1.f;
+  }
+  float rem_bias = 0.f;
+  unsigned int rem_step = 0u;
+  if (RIDE == ULTR_RIDE_REM) {
+    rem_bias = p.rem.bias_ptr ? p.rem.bias_ptr[0] : 0.f;
+    rem_step = p.rem.step + (p.rem.step_ctr ? p.rem.step_ctr[0] : 0u);
+  }
   float wv[KQ], gv[KQ], bv[KQ], aW[KQ], aG[KQ], aB[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
@@ -1097,12 +1118,38 @@ __global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
       const DlaLane v = dla_lane(o, c, tower_pw, lv, p.dla.loss_func);
       go_group = group_sum<16>(r == lg ? v.ds : 0.f);
     }
+    if (RIDE == ULTR_RIDE_IPW) {  // the same with per-element weights
+      const long long mg = min(mb + 4 * (lane >> 4), m_end - 1);
+      const int r = lane & 15, lg = (int)(mg / p.ipw.B);
+      const long long e = (long long)r * p.ipw.B + (mg - (long long)lg * p.ipw.B);
+      const bool lv = r < p.ipw.L;
+      const float o = lv ? p.ipw.scores[e] : 0.f, c = lv ? p.ipw.clicks[e] : 0.f, wgt = lv ? p.ipw.pw[e] : 0.f;
+      const DlaLane v = dla_lane(o, c, wgt, lv, p.ipw.loss_func);
+      go_group = group_sum<16>(r == lg ? v.ds : 0.f);
+    }
+    if (RIDE == ULTR_RIDE_PD) {  // every rank of the row's list against every other (group shuffles)
+      const long long mg = min(mb + 4 * (lane >> 4), m_end - 1);
+      const int r = lane & 15, lg = (int)(mg / p.pd.B);
+      const long long e = (long long)r * p.pd.B + (mg - (long long)lg * p.pd.B);
+      const bool lv = r < p.pd.L;
+      const float o = lv ? p.pd.scores[e] : 0.f, c = lv ? p.pd.clicks[e] : 0.f;
+      float unused[16];
+      const float ds = pd_lane<false>(o, c, pd_tp, pd_tm, lv, r, p.pd.L, lane & 48, unused);
+      go_group = group_sum<16>(r == lg ? ds : 0.f);
+    }
+    if (RIDE == ULTR_RIDE_REM) {  // elementwise: lane 16 u evaluates the row mb + 4 u
+      const long long mg = min(mb + 4 * (lane >> 4), m_end - 1);
+      const int lg = (int)(mg / p.rem.B);
+      const long long bg = mg - (long long)lg * p.rem.B;
+      go_group = rem_elem(p.rem, rem_bias, p.rem.propensity[lg], rem_step, bg, lg, mg).d;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long m = mb + 4 * u;
       live[u] = m < m_end;
       const long long mc = live[u] ? m : m_end - 1;
-      go[u] = DLA ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(go_group), 16 * u)) : p.d_scores[mc];
+      go[u] = RIDE != ULTR_RIDE_NONE ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(go_group), 16 * u))
+                                     : p.d_scores[mc];
       const float* src;
       mean[u] = 0.f; rstd[u] = 1.f;
       bool pad = false;
@@ -2150,30 +2197,38 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
     const size_t smem = sizeof(float) * 4 * (3 * (size_t)L.K[H] + 1);
     ULTR_REQUIRE(smem <= 64 * 1024, ULTR_ELIMIT, "ultr_dnn_backward: output layer input width %d too large", L.K[H]);
     ULTR_REQUIRE(H == 0 || L.K[H] <= 1024, ULTR_ELIMIT, "ultr_dnn_backward: hidden width %d beyond %d", L.K[H], 1024);
-    // A parked DLA loss (ultr_loss_dla_deferred) rides with this launch when it describes this very batch
-    bool fuse_dla = false;
-    if (g_pending_dla.on) {
-      const DlaArgs& pa = g_pending_dla.a;
-      fuse_dla = L.K[H] <= 1024 && pa.d_scores == d_scores && pa.L <= 16 && (long long)pa.B * pa.L == M;
-      g_pending_dla.on = false;
-      if (fuse_dla) {
-        b.dla = pa; b.dla_blocks = (int)g_pending_dla.nblocks; b.dla_pad = (b.dla_blocks + 7) & ~7;
+    // A parked loss (ultr_loss_{dla,ipw,rem}_deferred) rides with this launch when it describes this very batch
+    int ride = ULTR_RIDE_NONE;
+    if (g_pending_loss.kind != ULTR_RIDE_NONE) {
+      const PendingLoss pl = g_pending_loss;
+      g_pending_loss.kind = ULTR_RIDE_NONE;
+      if (L.K[H] <= 1024 && pl.d_scores() == d_scores && pl.rows() == M) {
+        ride = pl.kind;
+        b.ride = ride; b.dla = pl.dla; b.ipw = pl.ipw; b.rem = pl.rem; b.pd = pl.pd;
+        b.dla_blocks = (int)pl.nblocks; b.dla_pad = (b.dla_blocks + 7) & ~7;
       } else {
-        rc = launch_dla_now(pa, g_pending_dla.nblocks, st);
+        rc = launch_loss_now(pl, st);
         if (rc) return rc;
       }
     }
     {
-      ultr::ProfScope prof_(fuse_dla ? "bwd_out_kernel+dla_loss" : "bwd_out_kernel", st);
+      ultr::ProfScope prof_(ride == ULTR_RIDE_DLA ? "bwd_out_kernel+dla_loss" : ride == ULTR_RIDE_IPW ? "bwd_out_kernel+ipw_loss"
+                            : ride == ULTR_RIDE_REM ? "bwd_out_kernel+rem_loss" : ride == ULTR_RIDE_PD ? "bwd_out_kernel+pd_loss"
+                            : "bwd_out_kernel", st);
       const dim3 grid((unsigned)(L.out_blocks + b.dla_pad)), block(kThreads);
-      if (fuse_dla) {
-        if (L.K[H] <= 128) hipLaunchKernelGGL((bwd_out_kernel<2, true>), grid, block, smem, st, b);
-        else if (L.K[H] <= 256) hipLaunchKernelGGL((bwd_out_kernel<4, true>), grid, block, smem, st, b);
-        else hipLaunchKernelGGL((bwd_out_kernel<16, true>), grid, block, smem, st, b);
-      } else if (L.K[H] <= 128) hipLaunchKernelGGL((bwd_out_kernel<2, false>), grid, block, smem, st, b);
-      else if (L.K[H] <= 256) hipLaunchKernelGGL((bwd_out_kernel<4, false>), grid, block, smem, st, b);
-      else if (L.K[H] <= 1024) hipLaunchKernelGGL((bwd_out_kernel<16, false>), grid, block, smem, st, b);
+#define ULTR_BWD_OUT(KQ_)                                                                                      \
+  do {                                                                                                         \
+    if (ride == ULTR_RIDE_DLA) hipLaunchKernelGGL((bwd_out_kernel<KQ_, ULTR_RIDE_DLA>), grid, block, smem, st, b);      \
+    else if (ride == ULTR_RIDE_IPW) hipLaunchKernelGGL((bwd_out_kernel<KQ_, ULTR_RIDE_IPW>), grid, block, smem, st, b); \
+    else if (ride == ULTR_RIDE_REM) hipLaunchKernelGGL((bwd_out_kernel<KQ_, ULTR_RIDE_REM>), grid, block, smem, st, b); \
+    else if (ride == ULTR_RIDE_PD) hipLaunchKernelGGL((bwd_out_kernel<KQ_, ULTR_RIDE_PD>), grid, block, smem, st, b);   \
+    else hipLaunchKernelGGL((bwd_out_kernel<KQ_, ULTR_RIDE_NONE>), grid, block, smem, st, b);                            \
+  } while (0)
+      if (L.K[H] <= 128) ULTR_BWD_OUT(2);
+      else if (L.K[H] <= 256) ULTR_BWD_OUT(4);
+      else if (L.K[H] <= 1024) ULTR_BWD_OUT(16);
       else hipLaunchKernelGGL(bwd_out_wide_kernel, grid, block, smem, st, b);
+#undef ULTR_BWD_OUT
     }
     rc = check_launch("bwd_out_kernel");
     if (rc) return rc;

@@ -70,60 +70,10 @@ __global__ void __launch_bounds__(kLossThreads) ipw_loss_kernel(const float* __r
 
 // IPW for short lists (L <= 16): one lane per (list, rank), 16 lists per block; the per-list softmax is a group
 // reduction over 16 lanes, the per-rank maxima meet by lane exchange.  Same arithmetic as ipw_loss_kernel.
-__global__ void __launch_bounds__(kLossThreads) ipw_loss_small_kernel(const float* __restrict__ scores,
-                                                                      const float* __restrict__ clicks,
-                                                                      const float* __restrict__ pw, int B, int L,
-                                                                      int loss_func, float* __restrict__ d_scores,
-                                                                      float* __restrict__ stats,
-                                                                      float* __restrict__ list_weights, float* ws) {
+__global__ void __launch_bounds__(kLossThreads) ipw_loss_small_kernel(IpwArgs a) {
   __shared__ float s_acc[kMaxStat];
   __shared__ float s_part[4 * kMaxStat];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = tid & 15, li = tid >> 4;
-  const bool in_list = r < L;
-  float num = 0.f, den = 0.f, wmax = -INFINITY;
-  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
-    const long long b = b0 + li;
-    const bool live = in_list && b < B;
-    const long long e = (long long)r * B + (b < B ? b : 0);
-    const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f, w = live ? pw[e] : 0.f;
-    if (live) wmax = fmaxf(wmax, w);
-    const float lw = group_sum<16>(live ? w * fminf(fmaxf(c, 0.f), 1.f) : 0.f);
-    if (loss_func == ULTR_LOSS_SOFTMAX) {
-      const float m = group_max<16>(live ? o : -INFINITY);
-      const float se = group_sum<16>(live ? expf(o - m) : 0.f);
-      const float wl = live ? (c + 0.0000001f) * w : 0.f;
-      const float S = group_sum<16>(wl);
-      const float lse = m + logf(se);
-      if (live) {
-        num -= wl * (o - lse);
-        d_scores[e] = expf(o - lse) * S - wl;
-        den += r == 0 ? S : 0.f;
-      }
-    } else if (live) {
-      const float z = fminf(c, 1.f);
-      num += sig_ce(z, o) * w;
-      d_scores[e] = (sigmoidf_(o) - z) * w;
-      den += r == 0 ? 1.f : 0.f;
-    }
-    if (live && r == 0 && list_weights) list_weights[b] = lw / (float)L;
-  }
-  num = wave_sum(num);
-  den = wave_sum(den);
-  float o1, o2;
-  wmax = xor16_partner(wmax, &o1);
-  wmax = fmaxf(wmax, o1);
-  wmax = xor32_partner(wmax, &o2);
-  wmax = fmaxf(wmax, o2);
-  float* mine = s_part + wid * kMaxStat;
-  if (lane == 0) {
-    mine[0] = num;
-    mine[1] = den;
-  }
-  if (lane < L) mine[2 + lane] = wmax;
-  BlockStats bs{s_part};
-  bs.combine(s_acc, 2 + L, 2);
-  finish_stats(s_acc, 2 + L, 2, ws, stats);
+  ipw_loss_small_body(a, blockIdx.x, gridDim.x, s_acc, s_part);
 }
 
 __global__ void ipw_weights_kernel(const float* __restrict__ clicks, int B, int L, const float* __restrict__ ipw,
@@ -344,81 +294,10 @@ __global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
 // Regression-EM for short lists (L <= 16): one lane per (list, rank), 16 lists per block -- the batch-256 step then
 // runs on 16 CUs with one pass of per-rank exchanges instead of one CU walking the ranks with 3 L wave reductions.
 // Same arithmetic and the same Philox words per (list, rank) as rem_loss_kernel.
-__global__ void __launch_bounds__(kLossThreads) rem_loss_small_kernel(
-    const float* __restrict__ scores, const float* __restrict__ clicks, int B, int L,
-    const float* __restrict__ propensity, const float* __restrict__ bias_ptr, const float* __restrict__ uniforms,
-    unsigned long long seed, unsigned int step, const unsigned int* step_ctr, unsigned int slot_base,
-    float* __restrict__ d_scores, float* __restrict__ ranker_labels, float* __restrict__ list_weights,
-    float* __restrict__ stats, float* d_bias, float* ws) {
+__global__ void __launch_bounds__(kLossThreads) rem_loss_small_kernel(RemArgs a) {
   __shared__ float s_acc[kMaxStat];
   __shared__ float s_part[4 * kMaxStat];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = tid & 15, li = tid >> 4;
-  const bool in_list = r < L;
-  const float bias = bias_ptr ? bias_ptr[0] : 0.f;
-  const float p = in_list ? propensity[r] : 1.f;
-  if (step_ctr) step += step_ctr[0];  // device-resident step counter (read-only here), see feed.hip
-  float loss = 0.f, cnt = 0.f, dsum = 0.f, ms = 0.f, ys = 0.f, cs = 0.f;
-  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
-    const long long b = b0 + li;
-    const bool live = in_list && b < B;
-    const long long e = (long long)r * B + (b < B ? b : 0);
-    float lwt = 0.f;
-    if (live) {
-      const float x = scores[e] + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
-      const float c = clicks[e];
-      const float g = sigmoidf_(x);
-      const float den = 1.f - p * g;
-      const float p_e1_r0_c0 = p * (1.f - g) / den;  // :140-141
-      const float p_e0_r1_c0 = (1.f - p) * g / den;  // :142-143
-      const float p_r1 = c + (1.f - c) * p_e0_r1_c0;  // :147-148
-      float u;
-      if (uniforms) {
-        u = uniforms[e];
-      } else {
-        const Philox4 rnd = philox4x32_10(slot_base + (uint32_t)b, 0x52454Du, (uint32_t)(r >> 2), step, (uint32_t)seed,
-                                          (uint32_t)(seed >> 32));
-        u = u24(rnd.v[r & 3]);
-      }
-      float y = ceilf(p_r1 - u);  // get_bernoulli_sample (:39)
-      y = y > 0.f ? y : 0.f;      // ceil(-0.x) = -0 -> 0
-      loss += sig_ce(y, x);       // :159-165
-      const float d = g - y;
-      d_scores[e] = d;
-      dsum += d;
-      if (ranker_labels) ranker_labels[e] = y;
-      ms += c + (1.f - c) * p_e1_r0_c0;  // :153
-      ys += y;
-      cs += c;
-      lwt = fminf(fmaxf(c, 0.f), 1.f) / p;  // propensity_weights = 1/propensity (:176)
-      cnt += r == 0 ? 1.f : 0.f;
-    }
-    const float lw = group_sum<16>(lwt);
-    if (live && r == 0 && list_weights) list_weights[b] = lw / (float)L;
-  }
-  loss = wave_sum(loss);
-  cnt = wave_sum(cnt);
-  dsum = wave_sum(dsum);
-  float o1, o2;
-  ms = xor16_partner(ms, &o1); ms += o1; ms = xor32_partner(ms, &o2) + o2;
-  ys = xor16_partner(ys, &o1); ys += o1; ys = xor32_partner(ys, &o2) + o2;
-  cs = xor16_partner(cs, &o1); cs += o1; cs = xor32_partner(cs, &o2) + o2;
-  float* mine = s_part + wid * kMaxStat;
-  if (lane == 0) {
-    mine[0] = loss;
-    mine[1] = cnt;
-    mine[2 + 3 * L] = dsum;
-  }
-  if (lane < L) {
-    mine[2 + lane] = ms;
-    mine[2 + L + lane] = ys;
-    mine[2 + 2 * L + lane] = cs;
-  }
-  BlockStats bs{s_part};
-  bs.combine(s_acc, 3 + 3 * L, 1 << 30);
-  if (finish_stats(s_acc, 3 + 3 * L, 1 << 30, ws, stats)) {
-    if (threadIdx.x == 0 && d_bias) d_bias[0] = s_acc[2 + 3 * L];  // un-normalised d loss / d sigmoid_prob_b
-  }
+  rem_loss_small_body(a, blockIdx.x, gridDim.x, s_acc, s_part);
 }
 
 __global__ void rem_update_kernel(float* propensity, int L, const float* stats, float s, float* old_out) {
@@ -513,73 +392,11 @@ __global__ void __launch_bounds__(kLossThreads) pd_loss_kernel(const float* __re
 // instead of L^2 (the one-thread-per-list kernel above ran the whole headline batch on ONE CU: 85 us).  Lane (b, k)
 // forms the pair losses l_kj and the gradient wrt o_k in the same walk over j.  Batch sums: the four lists of a
 // wave meet by lane exchange, the waves in LDS, the blocks in the workspace (fixed order, last block reduces).
-__global__ void __launch_bounds__(kLossThreads) pd_loss_small_kernel(const float* __restrict__ scores,
-                                                                     const float* __restrict__ clicks, int B, int L,
-                                                                     const float* __restrict__ t_plus,
-                                                                     const float* __restrict__ t_minus,
-                                                                     float* __restrict__ d_scores,
-                                                                     float* __restrict__ stats, float* ws) {
+__global__ void __launch_bounds__(kLossThreads) pd_loss_small_kernel(PdArgs a) {
   __shared__ float s_acc[kMaxStat];
   __shared__ float s_part[4 * kMaxStat];
-  __shared__ float s_tp[16], s_tm[16];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = tid & 15, li = tid >> 4, gbase = lane & 48;
-  const bool in_list = r < L;
-  const float tp_k = in_list ? t_plus[r] : 1.f, tm_k = in_list ? t_minus[r] : 1.f;
-  if (tid < 16) {
-    s_tp[tid] = tp_k;
-    s_tm[tid] = tm_k;
-  }
-  float pl[16];  // l_kj summed over this lane's lists, j = 0..15
-#pragma unroll
-  for (int j = 0; j < 16; ++j) pl[j] = 0.f;
-  for (long long b0 = (long long)blockIdx.x * 16; b0 < B; b0 += (long long)gridDim.x * 16) {
-    const long long b = b0 + li;
-    const bool live = in_list && b < B;
-    const long long e = (long long)r * B + (b < B ? b : 0);
-    const float o = live ? scores[e] : 0.f, c = live ? clicks[e] : 0.f;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j < L) {  // uniform
-        const float oj = __shfl(o, gbase + j, 64), cj = __shfl(c, gbase + j, 64);
-        const float tpj = __shfl(tp_k, gbase + j, 64), tmj = __shfl(tm_k, gbase + j, 64);
-        const float m1 = fminf(1.f, fmaxf(c - cj, 0.f));  // min(1, relu(c_k - c_j))  (:147-150)
-        const float m2 = fminf(1.f, fmaxf(cj - c, 0.f));
-        if (live && j != r && (m1 > 0.f || m2 > 0.f)) {
-          // one exponential serves both: softplus(d) = max(d, 0) + log1p(e), sigmoid(d) = (d >= 0 ? 1 : e) / (1 + e)
-          const float diff = oj - o;
-          const float ex = expf(-fabsf(diff));
-          const float inv = 1.f / (1.f + ex);
-          const float sg = diff >= 0.f ? inv : ex * inv;   // d softplus(o_j - o_k) / d o_j
-          pl[j] += m1 * (fmaxf(diff, 0.f) + log1pf(ex));   // softplus(o_j - o_k)  (:151-155)
-          acc += m2 / (tpj * tm_k) * (1.f - sg) - m1 / (tp_k * tmj) * sg;  // pair (j, k): sig(o_k - o_j) ; pair (k, j)
-        }
-      }
-    }
-    if (live) d_scores[e] = acc;
-  }
-  // the four lists of the wave (same rank k: lanes k, k+16, k+32, k+48), then the waves
-  float* mine = s_part + wid * kMaxStat;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    float o1, o2;
-    float v = xor16_partner(pl[j], &o1);
-    v += o1;
-    v = xor32_partner(v, &o2) + o2;
-    if (lane < L && j < L) mine[lane * L + j] = v;
-  }
-  if (lane == 0) mine[L * L] = 0.f;
-  BlockStats bs{s_part};
-  bs.combine(s_acc, L * L + 1, 1 << 30);
-  if (finish_stats(s_acc, L * L + 1, 1 << 30, ws, stats)) {  // block-uniform
-    // loss = sum_ij l_ij / t+_i / t-_j  (:158-159), pre-update ratios: one term per thread, then a block sum
-    __shared__ float red[4];
-    float term[1] = {0.f};
-    if (tid < L * L && tid / L != tid % L) term[0] = s_acc[tid] / s_tp[tid / L] / s_tm[tid % L];
-    block_sum<1>(term, red);
-    if (tid == 0) stats[L * L] = term[0];
-  }
+  __shared__ float s_t[32];
+  pd_loss_small_body(a, blockIdx.x, gridDim.x, s_acc, s_part, s_t);
 }
 
 // t+_i <- (1-s) t+_i + s (A_i/A_0)^(1/(p+1)), A_i = sum_j l_ij/t-_j ; t-_j likewise (:162-171)
@@ -628,6 +445,32 @@ __global__ void pd_update_kernel(float* t_plus, float* t_minus, int L, float* st
 
 using namespace ultr;
 
+namespace ultr {
+thread_local PendingLoss g_pending_loss = {};
+
+static inline unsigned small_blocks(int B) { return (unsigned)(cdiv(B, 16) < 1024 ? cdiv(B, 16) : 1024); }
+
+int launch_loss_now(const PendingLoss& p, hipStream_t st) {
+  const char* name = p.kind == ULTR_RIDE_DLA ? "dla_loss_kernel" : p.kind == ULTR_RIDE_IPW ? "ipw_loss_kernel"
+                     : p.kind == ULTR_RIDE_REM ? "rem_loss_kernel" : "pd_loss_kernel";
+  {
+    ultr::ProfScope prof_(name, st);
+    if (p.kind == ULTR_RIDE_DLA) hipLaunchKernelGGL(dla_loss_small_kernel, dim3(p.nblocks), dim3(kLossThreads), 0, st, p.dla);
+    else if (p.kind == ULTR_RIDE_IPW) hipLaunchKernelGGL(ipw_loss_small_kernel, dim3(p.nblocks), dim3(kLossThreads), 0, st, p.ipw);
+    else if (p.kind == ULTR_RIDE_REM) hipLaunchKernelGGL(rem_loss_small_kernel, dim3(p.nblocks), dim3(kLossThreads), 0, st, p.rem);
+    else hipLaunchKernelGGL(pd_loss_small_kernel, dim3(p.nblocks), dim3(kLossThreads), 0, st, p.pd);
+  }
+  return check_launch(name);
+}
+}  // namespace ultr
+
+extern "C" int ultr_loss_flush(void* stream) {
+  if (g_pending_loss.kind == ULTR_RIDE_NONE) return ULTR_OK;
+  const PendingLoss p = g_pending_loss;
+  g_pending_loss.kind = ULTR_RIDE_NONE;
+  return launch_loss_now(p, as_stream(stream));
+}
+
 extern "C" long long ultr_loss_workspace_floats(int B, int L) {
   const long long blocks = cdiv(B > 0 ? B : 1, 16);  // the short-list DLA kernel runs 16 lists per block
   long long ns = 4 + 4 * (long long)L;
@@ -642,24 +485,29 @@ static int loss_args_ok(const char* who, const void* scores, const void* clicks,
   return ULTR_OK;
 }
 
+static int ipw_args(const char* who, IpwArgs* a, const float* scores, const float* clicks, const float* pw, int B, int L,
+                    int loss_func, float* d_scores, float* stats, float* list_weights, float* ws) {
+  int rc = loss_args_ok(who, scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(pw && d_scores && stats, ULTR_EINVAL, "%s: null pointer", who);
+  ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
+               "%s: loss_func=%d (pairwise_loss raises NameError in the reference and is not supported)", who, loss_func);
+  *a = IpwArgs{scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws};
+  return ULTR_OK;
+}
+
 extern "C" int ultr_loss_ipw_fwdbwd(const float* scores, const float* clicks, const float* pw, int B, int L,
                                     int loss_func, float* d_scores, float* stats, float* list_weights, float* ws,
                                     void* stream) {
-  int rc = loss_args_ok("ultr_loss_ipw_fwdbwd", scores, clicks, B, L, ws);
+  IpwArgs a;
+  int rc = ipw_args("ultr_loss_ipw_fwdbwd", &a, scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
   if (rc) return rc;
-  ULTR_REQUIRE(pw && d_scores && stats, ULTR_EINVAL, "ultr_loss_ipw_fwdbwd: null pointer");
-  ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
-               "ultr_loss_ipw_fwdbwd: loss_func=%d (pairwise_loss raises NameError in the reference and is not "
-               "supported)", loss_func);
+  rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
+  if (rc) return rc;
   if (L <= 16) {
-    long long blocks = cdiv(B, 16);
-    if (blocks > 1024) blocks = 1024;  // partial rows stay bounded; a block then walks several groups of 16 lists
-    {
-      ultr::ProfScope prof_("ipw_loss_kernel", as_stream(stream));
-      hipLaunchKernelGGL(ipw_loss_small_kernel, dim3((unsigned)blocks), dim3(kLossThreads), 0, as_stream(stream), scores,
-                       clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
-    }
-    return check_launch("ipw_loss_small_kernel");
+    PendingLoss p{};
+    p.kind = ULTR_RIDE_IPW; p.ipw = a; p.nblocks = small_blocks(B);
+    return launch_loss_now(p, as_stream(stream));
   }
   {
     ultr::ProfScope prof_("ipw_loss_kernel", as_stream(stream));
@@ -667,6 +515,22 @@ extern "C" int ultr_loss_ipw_fwdbwd(const float* scores, const float* clicks, co
                      scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
   }
   return check_launch("ipw_loss_kernel");
+}
+
+extern "C" int ultr_loss_ipw_deferred(const float* scores, const float* clicks, const float* pw, int B, int L,
+                                      int loss_func, float* d_scores, float* stats, float* list_weights, float* ws,
+                                      void* stream) {
+  if (L > 16)
+    return ultr_loss_ipw_fwdbwd(scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws, stream);
+  IpwArgs a;
+  int rc = ipw_args("ultr_loss_ipw_deferred", &a, scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
+  if (rc) return rc;
+  rc = ultr_loss_flush(stream);
+  if (rc) return rc;
+  g_pending_loss.kind = ULTR_RIDE_IPW;
+  g_pending_loss.ipw = a;
+  g_pending_loss.nblocks = small_blocks(B);
+  return ULTR_OK;
 }
 
 extern "C" int ultr_ipw_weights(const float* clicks, int B, int L, const float* ipw, int n_ipw, float* pw,
@@ -680,19 +544,6 @@ extern "C" int ultr_ipw_weights(const float* clicks, int B, int L, const float* 
   return check_launch("ipw_weights_kernel");
 }
 
-namespace ultr {
-thread_local PendingDla g_pending_dla = {};
-
-static inline unsigned dla_small_blocks(int B) { return (unsigned)(cdiv(B, 16) < 1024 ? cdiv(B, 16) : 1024); }
-
-int launch_dla_now(const DlaArgs& a, unsigned nblocks, hipStream_t st) {
-  {
-    ultr::ProfScope prof_("dla_loss_kernel", st);
-    hipLaunchKernelGGL(dla_loss_small_kernel, dim3(nblocks), dim3(kLossThreads), 0, st, a);
-  }
-  return check_launch("dla_loss_kernel");
-}
-}  // namespace ultr
 
 static int dla_args(const char* who, DlaArgs* a, const float* scores, const float* clicks, int B, int L,
                     const float* prop_params, int loss_func, int logits_to_prob, float max_propensity_weight,
@@ -709,11 +560,6 @@ static int dla_args(const char* who, DlaArgs* a, const float* scores, const floa
   return ULTR_OK;
 }
 
-extern "C" int ultr_loss_flush(void* stream) {
-  if (!g_pending_dla.on) return ULTR_OK;
-  g_pending_dla.on = false;
-  return launch_dla_now(g_pending_dla.a, g_pending_dla.nblocks, as_stream(stream));
-}
 
 extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* prop_params,
                                     int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
@@ -724,7 +570,11 @@ extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, in
   if (rc) return rc;
   rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
   if (rc) return rc;
-  if (L <= 16) return launch_dla_now(a, dla_small_blocks(B), as_stream(stream));
+  if (L <= 16) {
+    PendingLoss p{};
+    p.kind = ULTR_RIDE_DLA; p.dla = a; p.nblocks = small_blocks(B);
+    return launch_loss_now(p, as_stream(stream));
+  }
   {
     ultr::ProfScope prof_("dla_loss_kernel", as_stream(stream));
     hipLaunchKernelGGL(dla_loss_kernel<64>, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0,
@@ -746,9 +596,9 @@ extern "C" int ultr_loss_dla_deferred(const float* scores, const float* clicks, 
   if (rc) return rc;
   rc = ultr_loss_flush(stream);
   if (rc) return rc;
-  g_pending_dla.on = true;
-  g_pending_dla.a = a;
-  g_pending_dla.nblocks = dla_small_blocks(B);
+  g_pending_loss.kind = ULTR_RIDE_DLA;
+  g_pending_loss.dla = a;
+  g_pending_loss.nblocks = small_blocks(B);
   return ULTR_OK;
 }
 
@@ -760,16 +610,14 @@ extern "C" int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, in
   int rc = loss_args_ok("ultr_loss_rem_fwdbwd", scores, clicks, B, L, ws);
   if (rc) return rc;
   ULTR_REQUIRE(propensity && d_scores && stats, ULTR_EINVAL, "ultr_loss_rem_fwdbwd: null pointer");
+  rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
+  if (rc) return rc;
   if (L <= 16) {
-    long long blocks = cdiv(B, 16);
-    if (blocks > 1024) blocks = 1024;  // partial rows stay bounded; a block then walks several groups of 16 lists
-    {
-      ultr::ProfScope prof_("rem_loss_kernel", as_stream(stream));
-      hipLaunchKernelGGL(rem_loss_small_kernel, dim3((unsigned)blocks), dim3(kLossThreads), 0, as_stream(stream), scores,
-                       clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base, d_scores,
-                       ranker_labels, list_weights, stats, d_bias, ws);
-    }
-    return check_launch("rem_loss_small_kernel");
+    PendingLoss p{};
+    p.kind = ULTR_RIDE_REM; p.nblocks = small_blocks(B);
+    p.rem = RemArgs{scores, clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base, d_scores,
+                    ranker_labels, list_weights, stats, d_bias, ws};
+    return launch_loss_now(p, as_stream(stream));
   }
   {
     ultr::ProfScope prof_("rem_loss_kernel", as_stream(stream));
@@ -778,6 +626,26 @@ extern "C" int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, in
                      ranker_labels, list_weights, stats, d_bias, ws);
   }
   return check_launch("rem_loss_kernel");
+}
+
+extern "C" int ultr_loss_rem_deferred(const float* scores, const float* clicks, int B, int L, const float* propensity,
+                                      const float* sigmoid_prob_b, const float* uniforms, unsigned long long seed,
+                                      unsigned int step, const unsigned int* step_ctr, unsigned int slot_base,
+                                      float* d_scores, float* ranker_labels, float* list_weights,
+                                      float* stats, float* d_bias, float* ws, void* stream) {
+  if (L > 16)
+    return ultr_loss_rem_fwdbwd(scores, clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base,
+                                d_scores, ranker_labels, list_weights, stats, d_bias, ws, stream);
+  int rc = loss_args_ok("ultr_loss_rem_deferred", scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(propensity && d_scores && stats, ULTR_EINVAL, "ultr_loss_rem_deferred: null pointer");
+  rc = ultr_loss_flush(stream);
+  if (rc) return rc;
+  g_pending_loss.kind = ULTR_RIDE_REM;
+  g_pending_loss.rem = RemArgs{scores, clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base,
+                               d_scores, ranker_labels, list_weights, stats, d_bias, ws};
+  g_pending_loss.nblocks = small_blocks(B);
+  return ULTR_OK;
 }
 
 extern "C" int ultr_rem_update_propensity(float* propensity, int L, const float* stats, float em_step_size,
@@ -796,15 +664,13 @@ extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int
   if (rc) return rc;
   ULTR_REQUIRE(t_plus && t_minus && d_scores && stats, ULTR_EINVAL, "ultr_loss_pd_fwdbwd: null pointer");
   ULTR_REQUIRE(L <= kPdMaxL, ULTR_ELIMIT, "ultr_loss_pd_fwdbwd: L=%d > %d", L, kPdMaxL);
+  rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
+  if (rc) return rc;
   if (L <= 16) {
-    long long blocks = cdiv(B, 16);
-    if (blocks > 1024) blocks = 1024;  // partial rows stay bounded; a block then walks several groups of 16 lists
-    {
-      ultr::ProfScope prof_("pd_loss_kernel", as_stream(stream));
-      hipLaunchKernelGGL(pd_loss_small_kernel, dim3((unsigned)blocks), dim3(kLossThreads), 0, as_stream(stream), scores,
-                       clicks, B, L, t_plus, t_minus, d_scores, stats, ws);
-    }
-    return check_launch("pd_loss_small_kernel");
+    PendingLoss p{};
+    p.kind = ULTR_RIDE_PD; p.nblocks = small_blocks(B);
+    p.pd = PdArgs{scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws};
+    return launch_loss_now(p, as_stream(stream));
   }
   const size_t smem = sizeof(float) * ((size_t)2 * L * kLossThreads + (size_t)L * L + 1 + (size_t)4 * L * L);
   if (smem > 48 * 1024)
@@ -816,6 +682,20 @@ extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int
                      as_stream(stream), scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws);
   }
   return check_launch("pd_loss_kernel");
+}
+
+extern "C" int ultr_loss_pd_deferred(const float* scores, const float* clicks, int B, int L, const float* t_plus,
+                                     const float* t_minus, float* d_scores, float* stats, float* ws, void* stream) {
+  if (L > 16) return ultr_loss_pd_fwdbwd(scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws, stream);
+  int rc = loss_args_ok("ultr_loss_pd_deferred", scores, clicks, B, L, ws);
+  if (rc) return rc;
+  ULTR_REQUIRE(t_plus && t_minus && d_scores && stats, ULTR_EINVAL, "ultr_loss_pd_deferred: null pointer");
+  rc = ultr_loss_flush(stream);
+  if (rc) return rc;
+  g_pending_loss.kind = ULTR_RIDE_PD;
+  g_pending_loss.pd = PdArgs{scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws};
+  g_pending_loss.nblocks = small_blocks(B);
+  return ULTR_OK;
 }
 
 extern "C" int ultr_pd_update_ratios(float* t_plus, float* t_minus, int L, float* stats, float em_step_size,

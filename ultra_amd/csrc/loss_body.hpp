@@ -222,13 +222,262 @@ __device__ __forceinline__ void dla_loss_small_body(const DlaArgs& a, unsigned i
   }
 }
 
-// A DLA loss request parked by ultr_loss_dla_deferred until the next ultr_dnn_backward of this host thread carries it.
-struct PendingDla {
-  bool on;
-  DlaArgs a;
-  unsigned nblocks;
+// ------------------------------------------------------------------------------------------
+// IPW for short lists (L <= 16): softmax_loss / sigmoid_loss_on_list with per-element weights (base_algorithm.py
+// :228-251, :163-186); also the naive algorithm's loss (weights of one).  Same lane layout as the DLA kernel, and the
+// same rank-loss lane function.
+// stats: [0] numerator  [1] normaliser  [2+l] max_b pw
+// ------------------------------------------------------------------------------------------
+struct IpwArgs {
+  const float* scores; const float* clicks; const float* pw; int B, L, loss_func;
+  float* d_scores; float* stats; float* list_weights; float* ws;
 };
-extern thread_local PendingDla g_pending_dla;
-int launch_dla_now(const DlaArgs& a, unsigned nblocks, hipStream_t st);  // loss.hip
+
+__device__ __forceinline__ void ipw_loss_small_body(const IpwArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                                    float* s_part) {
+  const int B = a.B, L = a.L, loss_func = a.loss_func;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & 15, li = tid >> 4;
+  const bool in_list = r < L;
+  float num = 0.f, den = 0.f, wmax = -INFINITY;
+  for (long long b0 = (long long)bid * 16; b0 < B; b0 += (long long)nb * 16) {
+    const long long b = b0 + li;
+    const bool live = in_list && b < B;
+    const long long e = (long long)r * B + (b < B ? b : 0);
+    const float o = live ? a.scores[e] : 0.f, c = live ? a.clicks[e] : 0.f, w = live ? a.pw[e] : 0.f;
+    if (live) wmax = fmaxf(wmax, w);
+    const float lw = group_sum<16>(live ? w * fminf(fmaxf(c, 0.f), 1.f) : 0.f);
+    const DlaLane v = dla_lane(o, c, w, live, loss_func);
+    if (live) {
+      a.d_scores[e] = v.ds;
+      if (loss_func == ULTR_LOSS_SOFTMAX) {
+        num -= v.wl * (o - v.lse);
+        den += r == 0 ? v.S : 0.f;
+      } else {
+        num += sig_ce(fminf(c, 1.f), o) * w;
+        den += r == 0 ? 1.f : 0.f;
+      }
+      if (r == 0 && a.list_weights) a.list_weights[b] = lw / (float)L;
+    }
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  float o1, o2;
+  wmax = xor16_partner(wmax, &o1);
+  wmax = fmaxf(wmax, o1);
+  wmax = xor32_partner(wmax, &o2);
+  wmax = fmaxf(wmax, o2);
+  float* mine = s_part + wid * kMaxStat;
+  if (lane == 0) {
+    mine[0] = num;
+    mine[1] = den;
+  }
+  if (lane < L) mine[2 + lane] = wmax;
+  BlockStats bs{s_part};
+  bs.combine(s_acc, 2 + L, 2);
+  finish_stats(s_acc, 2 + L, 2, a.ws, a.stats, bid, nb);
+}
+
+// ------------------------------------------------------------------------------------------
+// Regression-EM for short lists (regression_EM.py:116-176)
+// stats: [0] sum loss_b [1] B [2+l] M-step numerator [2+L+l] sum ranker_label [2+2L+l] sum clicks
+//        [2+3L] sum of d_scores (gradient of sigmoid_prob_b, un-normalised)
+// ------------------------------------------------------------------------------------------
+struct RemArgs {
+  const float* scores; const float* clicks; int B, L;
+  const float* propensity; const float* bias_ptr; const float* uniforms;
+  unsigned long long seed; unsigned int step; const unsigned int* step_ctr; unsigned int slot_base;
+  float* d_scores; float* ranker_labels; float* list_weights; float* stats; float* d_bias; float* ws;
+};
+
+// One (list b, rank r) element: E-step posteriors, the Bernoulli ranker label and d loss / d score = sigmoid - label.
+// Elementwise, so the backward pass's first launch can evaluate it for its own rows (ultr_loss_rem_deferred).
+struct RemElem { float x, g, y, d, p_e1_r0_c0; };
+__device__ __forceinline__ RemElem rem_elem(const RemArgs& a, float bias, float p, unsigned int step, long long b, int r,
+                                            long long e) {
+#pragma clang fp contract(off)
+  RemElem v;
+  const float c = a.clicks[e];
+  v.x = a.scores[e] + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
+  v.g = sigmoidf_(v.x);
+  const float den = 1.f - p * v.g;
+  v.p_e1_r0_c0 = p * (1.f - v.g) / den;              // :140-141
+  const float p_e0_r1_c0 = (1.f - p) * v.g / den;    // :142-143
+  const float p_r1 = c + (1.f - c) * p_e0_r1_c0;     // :147-148
+  float u;
+  if (a.uniforms) {
+    u = a.uniforms[e];
+  } else {
+    const Philox4 rnd = philox4x32_10(a.slot_base + (uint32_t)b, 0x52454Du, (uint32_t)(r >> 2), step, (uint32_t)a.seed,
+                                      (uint32_t)(a.seed >> 32));
+    u = u24(rnd.v[r & 3]);
+  }
+  v.y = ceilf(p_r1 - u);      // get_bernoulli_sample (:39)
+  v.y = v.y > 0.f ? v.y : 0.f;  // ceil(-0.x) = -0 -> 0
+  v.d = v.g - v.y;
+  return v;
+}
+
+__device__ __forceinline__ void rem_loss_small_body(const RemArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                                    float* s_part) {
+  const int B = a.B, L = a.L;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & 15, li = tid >> 4;
+  const bool in_list = r < L;
+  const float bias = a.bias_ptr ? a.bias_ptr[0] : 0.f;
+  const float p = in_list ? a.propensity[r] : 1.f;
+  const unsigned int step = a.step + (a.step_ctr ? a.step_ctr[0] : 0u);  // device-resident step counter (read-only here)
+  float loss = 0.f, cnt = 0.f, dsum = 0.f, ms = 0.f, ys = 0.f, cs = 0.f;
+  for (long long b0 = (long long)bid * 16; b0 < B; b0 += (long long)nb * 16) {
+    const long long b = b0 + li;
+    const bool live = in_list && b < B;
+    const long long e = (long long)r * B + (b < B ? b : 0);
+    float lwt = 0.f;
+    if (live) {
+      const RemElem v = rem_elem(a, bias, p, step, b, r, e);
+      const float c = a.clicks[e];
+      loss += sig_ce(v.y, v.x);       // :159-165
+      a.d_scores[e] = v.d;
+      dsum += v.d;
+      if (a.ranker_labels) a.ranker_labels[e] = v.y;
+      ms += c + (1.f - c) * v.p_e1_r0_c0;  // :153
+      ys += v.y;
+      cs += c;
+      lwt = fminf(fmaxf(c, 0.f), 1.f) / p;  // propensity_weights = 1/propensity (:176)
+      cnt += r == 0 ? 1.f : 0.f;
+    }
+    const float lw = group_sum<16>(lwt);
+    if (live && r == 0 && a.list_weights) a.list_weights[b] = lw / (float)L;
+  }
+  loss = wave_sum(loss);
+  cnt = wave_sum(cnt);
+  dsum = wave_sum(dsum);
+  float o1, o2;
+  ms = xor16_partner(ms, &o1); ms += o1; ms = xor32_partner(ms, &o2) + o2;
+  ys = xor16_partner(ys, &o1); ys += o1; ys = xor32_partner(ys, &o2) + o2;
+  cs = xor16_partner(cs, &o1); cs += o1; cs = xor32_partner(cs, &o2) + o2;
+  float* mine = s_part + wid * kMaxStat;
+  if (lane == 0) {
+    mine[0] = loss;
+    mine[1] = cnt;
+    mine[2 + 3 * L] = dsum;
+  }
+  if (lane < L) {
+    mine[2 + lane] = ms;
+    mine[2 + L + lane] = ys;
+    mine[2 + 2 * L + lane] = cs;
+  }
+  BlockStats bs{s_part};
+  bs.combine(s_acc, 3 + 3 * L, 1 << 30);
+  if (finish_stats(s_acc, 3 + 3 * L, 1 << 30, a.ws, a.stats, bid, nb)) {
+    if (threadIdx.x == 0 && a.d_bias) a.d_bias[0] = s_acc[2 + 3 * L];  // un-normalised d loss / d sigmoid_prob_b
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pairwise debiasing for short lists (pairwise_debias.py:139-171, pair CE base_algorithm.py:151-161)
+// stats: [0..L*L) pair-loss matrix l_ij (sum over lists)  [L*L] loss
+// ------------------------------------------------------------------------------------------
+struct PdArgs {
+  const float* scores; const float* clicks; int B, L;
+  const float* t_plus; const float* t_minus;
+  float* d_scores; float* stats; float* ws;
+};
+
+// Lane (list, rank k) against the other ranks j of its 16-lane group: d loss / d score_k, and (WITH_PL) the pair
+// losses l_kj added into pl[j].  Every lane of the wave must call it (group shuffles).
+template <bool WITH_PL>
+__device__ __forceinline__ float pd_lane(float o, float c, float tp_k, float tm_k, bool live, int r, int L, int gbase,
+                                         float (&pl)[16]) {
+#pragma clang fp contract(off)
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < L) {  // uniform
+      const float oj = __shfl(o, gbase + j, 64), cj = __shfl(c, gbase + j, 64);
+      const float tpj = __shfl(tp_k, gbase + j, 64), tmj = __shfl(tm_k, gbase + j, 64);
+      const float m1 = fminf(1.f, fmaxf(c - cj, 0.f));  // min(1, relu(c_k - c_j))  (:147-150)
+      const float m2 = fminf(1.f, fmaxf(cj - c, 0.f));
+      if (live && j != r && (m1 > 0.f || m2 > 0.f)) {
+        // one exponential serves both: softplus(d) = max(d, 0) + log1p(e), sigmoid(d) = (d >= 0 ? 1 : e) / (1 + e)
+        const float diff = oj - o;
+        const float ex = expf(-fabsf(diff));
+        const float inv = 1.f / (1.f + ex);
+        const float sg = diff >= 0.f ? inv : ex * inv;   // d softplus(o_j - o_k) / d o_j
+        if (WITH_PL) pl[j] += m1 * (fmaxf(diff, 0.f) + log1pf(ex));   // softplus(o_j - o_k)  (:151-155)
+        acc += m2 / (tpj * tm_k) * (1.f - sg) - m1 / (tp_k * tmj) * sg;  // pair (j, k): sig(o_k - o_j) ; pair (k, j)
+      }
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void pd_loss_small_body(const PdArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                                   float* s_part, float* s_t) {
+  const int B = a.B, L = a.L;
+  float* s_tp = s_t;
+  float* s_tm = s_t + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & 15, li = tid >> 4, gbase = lane & 48;
+  const bool in_list = r < L;
+  const float tp_k = in_list ? a.t_plus[r] : 1.f, tm_k = in_list ? a.t_minus[r] : 1.f;
+  if (tid < 16) {
+    s_tp[tid] = tp_k;
+    s_tm[tid] = tm_k;
+  }
+  float pl[16];  // l_kj summed over this lane's lists, j = 0..15
+#pragma unroll
+  for (int j = 0; j < 16; ++j) pl[j] = 0.f;
+  for (long long b0 = (long long)bid * 16; b0 < B; b0 += (long long)nb * 16) {
+    const long long b = b0 + li;
+    const bool live = in_list && b < B;
+    const long long e = (long long)r * B + (b < B ? b : 0);
+    const float o = live ? a.scores[e] : 0.f, c = live ? a.clicks[e] : 0.f;
+    const float acc = pd_lane<true>(o, c, tp_k, tm_k, live, r, L, gbase, pl);
+    if (live) a.d_scores[e] = acc;
+  }
+  // the four lists of the wave (same rank k: lanes k, k+16, k+32, k+48), then the waves
+  float* mine = s_part + wid * kMaxStat;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float o1, o2;
+    float v = xor16_partner(pl[j], &o1);
+    v += o1;
+    v = xor32_partner(v, &o2) + o2;
+    if (lane < L && j < L) mine[lane * L + j] = v;
+  }
+  if (lane == 0) mine[L * L] = 0.f;
+  BlockStats bs{s_part};
+  bs.combine(s_acc, L * L + 1, 1 << 30);
+  if (finish_stats(s_acc, L * L + 1, 1 << 30, a.ws, a.stats, bid, nb)) {  // block-uniform
+    // loss = sum_ij l_ij / t+_i / t-_j  (:158-159), pre-update ratios: one term per thread, then a block sum
+    __shared__ float red[4];
+    float term[1] = {0.f};
+    if (tid < L * L && tid / L != tid % L) term[0] = s_acc[tid] / s_tp[tid / L] / s_tm[tid % L];
+    block_sum<1>(term, red);
+    if (tid == 0) a.stats[L * L] = term[0];
+  }
+}
+
+// A loss request parked by ultr_loss_{dla,ipw,rem,pd}_deferred until the next ultr_dnn_backward of this host thread
+// carries it in its first launch.
+enum { ULTR_RIDE_NONE = 0, ULTR_RIDE_DLA = 1, ULTR_RIDE_IPW = 2, ULTR_RIDE_REM = 3, ULTR_RIDE_PD = 4 };
+struct PendingLoss {
+  int kind;
+  DlaArgs dla;
+  IpwArgs ipw;
+  RemArgs rem;
+  PdArgs pd;
+  unsigned nblocks;
+  const float* d_scores() const {
+    return kind == ULTR_RIDE_DLA ? dla.d_scores : kind == ULTR_RIDE_IPW ? ipw.d_scores : kind == ULTR_RIDE_REM ? rem.d_scores : pd.d_scores;
+  }
+  long long rows() const {
+    return kind == ULTR_RIDE_DLA ? (long long)dla.B * dla.L : kind == ULTR_RIDE_IPW ? (long long)ipw.B * ipw.L
+           : kind == ULTR_RIDE_REM ? (long long)rem.B * rem.L : (long long)pd.B * pd.L;
+  }
+};
+extern thread_local PendingLoss g_pending_loss;
+int launch_loss_now(const PendingLoss& p, hipStream_t st);  // loss.hip
 
 }  // namespace ultr

@@ -103,6 +103,19 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
   }
   const float sc = eff_scale(denom, scale_const);
   const long long nblk = gridDim.x - (rider.n > 0 ? 1 : 0);
+  // The block's first (usually only) batch of gradient / parameter / accumulator values is requested before the norm
+  // is formed: the update needs the norm, its operands do not, and the two memory round trips overlap.
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(grads);
+  float4* t4 = reinterpret_cast<float4*>(theta);
+  float4* a4 = reinterpret_cast<float4*>(accum);
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), t0 = g0, a0 = g0;
+  if (i0 < n4) {
+    g0 = g4[i0];
+    t0 = t4[i0];
+    if (strategy == ULTR_OPT_ADAGRAD) a0 = a4[i0];
+  }
   // every block reduces the same partials in the same (fixed) order, so all blocks see one norm
   float ssq[1] = {0.f};
   float nrm;
@@ -125,17 +138,13 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
     }
   }
   const float f = clip_norm > 0.f ? clip_norm / fmaxf(nrm, clip_norm) : 1.f;
-  const long long n4 = n >> 2;
-  const float4* g4 = reinterpret_cast<const float4*>(grads);
-  float4* t4 = reinterpret_cast<float4*>(theta);
-  float4* a4 = reinterpret_cast<float4*>(accum);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += nblk * blockDim.x) {
-    const float4 g = g4[i];
-    float4 t = t4[i];
+  for (long long i = i0; i < n4; i += nblk * blockDim.x) {
+    const float4 g = i == i0 ? g0 : g4[i];
+    float4 t = i == i0 ? t0 : t4[i];
     float gv[4] = {g.x, g.y, g.z, g.w};
     float tv[4] = {t.x, t.y, t.z, t.w};
     if (strategy == ULTR_OPT_ADAGRAD) {
-      float4 a = a4[i];
+      float4 a = i == i0 ? a0 : a4[i];
       float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

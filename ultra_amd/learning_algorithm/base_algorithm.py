@@ -261,6 +261,11 @@ class BaseAlgorithm(ABC):
     # ULTR_LOSS_RIDE=0: the loss kernel gets a launch of its own instead of riding with the backward pass's first one
     ride_loss = os.environ.get('ULTR_LOSS_RIDE', '1') != '0'
 
+    def _loss_rides(self):
+        """The loss may be parked for the backward pass's first launch when nothing needs its outputs before that: the
+        in-step metrics, which read the list weights, must ride with a later launch of the same pass."""
+        return self.ride_loss and self.ride_metrics and not self.side_metrics
+
     # ULTR_FUSED_TAIL=0: norm pass and result copy as launches of their own
     fused_tail = os.environ.get('ULTR_FUSED_TAIL', '1') != '0'
 
@@ -320,7 +325,15 @@ class BaseAlgorithm(ABC):
         batch = self._to_device_batch(input_feed, L)
         tb = self._train_buffers(batch.B)
         scores = self.ranking_model(L, batch, tb['scores'])
-        self._loss(tb, batch, scores)                          # d_scores + additive statistics
+        try:
+            self._loss(tb, batch, scores)                      # d_scores + additive statistics (may be parked)
+            self._backward_and_metrics(tb, batch, scores)
+        finally:
+            # a parked loss that no backward pass carried (an error in between) is launched while its buffers are alive
+            _lib.lib().ultr_loss_flush(_lib.current_stream())
+        self._pending = (tb, batch)
+
+    def _backward_and_metrics(self, tb, batch, scores):
         # The in-step metrics need only the scores and the list weights: they run on a side stream (a parallel
         # branch of the hipGraph when the step is captured) next to the backward pass, and are joined before
         # the all-reduce, which carries them together with the gradient and the loss statistics.
@@ -341,8 +354,6 @@ class BaseAlgorithm(ABC):
             self.model.backward(tb['d_scores'], tb['grads'], tb['sumsq'] if tb['sumsq_valid'] else None)
             if self.ride_metrics:
                 _lib.check(_lib.lib().ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
-        _lib.check(_lib.lib().ultr_loss_flush(_lib.current_stream()), 'ultr_loss_flush')  # no-op if carried
-        self._pending = (tb, batch)
 
     def step_reduce(self):
         """DP: the one collective of the step (sum of [grads | statistics | metrics] over ranks)."""

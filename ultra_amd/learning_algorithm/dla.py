@@ -73,8 +73,7 @@ class DLA(BaseAlgorithm):
         # The loss rides with the first launch of the backward pass (ultr_loss_dla_deferred) when nothing needs its
         # outputs before that: the in-step metrics, which read the list weights, ride with a later launch of the
         # same pass.  ULTR_LOSS_RIDE=0: a launch of its own.
-        ride = self.ride_loss and self.ride_metrics and not self.side_metrics
-        fn = _lib.lib().ultr_loss_dla_deferred if ride else _lib.lib().ultr_loss_dla_fwdbwd
+        fn = _lib.lib().ultr_loss_dla_deferred if self._loss_rides() else _lib.lib().ultr_loss_dla_fwdbwd
         _lib.check(fn(
             _lib.ptr(scores), _lib.ptr(batch.labels), batch.B, L, _lib.ptr(self.prop_params), self.loss_kind,
             self.prob_kind, float(h.max_propensity_weight), _lib.ptr(tb['d_scores']), _lib.ptr(pg),

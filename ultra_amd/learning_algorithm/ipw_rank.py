@@ -47,7 +47,8 @@ class IPWrank(BaseAlgorithm):
         # propensity_weights placeholders filled per list (ipw_rank.py:214-223)
         _lib.check(_lib.lib().ultr_ipw_weights(_lib.ptr(batch.labels), batch.B, L, _lib.ptr(self.ipw_table), L,
                                                _lib.ptr(self._pw), _lib.current_stream()), 'ultr_ipw_weights')
-        _lib.check(_lib.lib().ultr_loss_ipw_fwdbwd(
+        fn = _lib.lib().ultr_loss_ipw_deferred if self._loss_rides() else _lib.lib().ultr_loss_ipw_fwdbwd
+        _lib.check(fn(
             _lib.ptr(scores), _lib.ptr(batch.labels), _lib.ptr(self._pw), batch.B, L, self.loss_kind,
             _lib.ptr(tb['d_scores']), _lib.ptr(tb['stats']), _lib.ptr(tb['list_weights']), _lib.ptr(tb['loss_ws']),
             _lib.current_stream()), 'ultr_loss_ipw_fwdbwd')

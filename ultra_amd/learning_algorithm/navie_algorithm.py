@@ -39,7 +39,8 @@ class NavieAlgorithm(BaseAlgorithm):
         L = self.rank_list_size
         if self._ones is None or self._ones.shape[1] != batch.B:
             self._ones = torch.ones((L, batch.B), dtype=torch.float32, device=self.device)
-        _lib.check(_lib.lib().ultr_loss_ipw_fwdbwd(
+        fn = _lib.lib().ultr_loss_ipw_deferred if self._loss_rides() else _lib.lib().ultr_loss_ipw_fwdbwd
+        _lib.check(fn(
             _lib.ptr(scores), _lib.ptr(batch.labels), _lib.ptr(self._ones), batch.B, L, self.loss_kind,
             _lib.ptr(tb['d_scores']), _lib.ptr(tb['stats']), _lib.ptr(tb['list_weights']), _lib.ptr(tb['loss_ws']),
             _lib.current_stream()), 'ultr_loss_ipw_fwdbwd')

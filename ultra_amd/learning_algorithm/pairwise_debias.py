@@ -49,7 +49,8 @@ class PairDebias(BaseAlgorithm):
         return self._train_step(input_feed)
 
     def _loss(self, tb, batch, scores):
-        _lib.check(_lib.lib().ultr_loss_pd_fwdbwd(
+        fn = _lib.lib().ultr_loss_pd_deferred if self._loss_rides() else _lib.lib().ultr_loss_pd_fwdbwd
+        _lib.check(fn(
             _lib.ptr(scores), _lib.ptr(batch.labels), batch.B, self.rank_list_size, _lib.ptr(self.t_plus),
             _lib.ptr(self.t_minus), _lib.ptr(tb['d_scores']), _lib.ptr(tb['stats']), _lib.ptr(tb['loss_ws']),
             _lib.current_stream()), 'ultr_loss_pd_fwdbwd')

@@ -45,7 +45,9 @@ class RegressionEM(BaseAlgorithm):
 
     def _loss(self, tb, batch, scores):
         L = self.rank_list_size
-        _lib.check(_lib.lib().ultr_loss_rem_fwdbwd(
+        # parked for the backward pass's first launch (ultr_loss_rem_deferred) unless something reads its outputs earlier
+        fn = _lib.lib().ultr_loss_rem_deferred if self._loss_rides() else _lib.lib().ultr_loss_rem_fwdbwd
+        _lib.check(fn(
             _lib.ptr(scores), _lib.ptr(batch.labels), batch.B, L, _lib.ptr(self.propensity),
             _lib.ptr(self.sigmoid_prob_b), _lib.ptr(self.uniforms), self.seed, self.global_step.value & 0xFFFFFFFF,
             _lib.ptr(self.step_ctr), self.rank * batch.B, _lib.ptr(tb['d_scores']), None,
