@@ -299,23 +299,28 @@ struct FwdArgs {
 };
 
 static inline int panel_stride(int K) { return ((K < kPanelMaxK ? K : kPanelMaxK) + 31) / 32 * 32 + 4; }
-template <int WN, int WK>
+template <int WN, int WK, int RT = 1>
 static inline size_t fwd_smem_floats(int K, bool fuse) {
-  const size_t panel = 32 * (size_t)panel_stride(K), exch = (size_t)(WK > 1 ? WK : 0) * WN * 1024;
+  const size_t panel = 32 * RT * (size_t)panel_stride(K), exch = (size_t)(WK > 1 ? WK : 0) * WN * 1024;
   return (panel > exch ? panel : exch) + (fuse ? (size_t)WN * 32 * 36 + 32 * 3 * WN : 0);
 }
 
-template <int WN, int WK, bool FUSE, bool GATHER, int QMAX>
-__global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
+// RT = 2 (large batches, WK == 1, no fused output layer): the workgroup stages 64 rows and every wave keeps two
+// accumulator tiles, so that a streamed weight value feeds two MFMAs -- at 32 rows per workgroup the weight stream
+// (one float per lane per MFMA) is what the L1/L2 path cannot deliver at more than about half the MFMA rate.
+template <int WN, int WK, bool FUSE, bool GATHER, int QMAX, int RT = 1>
+__global__ void __launch_bounds__(64 * WN * WK, RT == 1 ? 2 : 1) fwd_layer_kernel(FwdArgs p) {
+  static_assert(RT == 1 || (WK == 1 && !FUSE), "two row tiles: plain layers without a contraction split only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NW = WN * WK;
+  constexpr int ROWS = 32 * RT;
   const int PS = ((min(p.K, kPanelMaxK) + 31) & ~31) + 4;  // panel row stride: == 4 (mod 32), conflict-free b128 rows
-  float* s_panel = smem;                             // [32][PS] normalised input rows
+  float* s_panel = smem;                             // [ROWS][PS] normalised input rows
   float* s_acc = smem;                               // [WK][WN][16][64] split-K exchange, reuses the panel (WK > 1)
-  float* s_epi = smem + max(32 * PS, (WK > 1 ? WK : 0) * WN * 1024);       // FUSE: [WN][32][36] transpose tiles, then [32][WN][3]
+  float* s_epi = smem + max(ROWS * PS, (WK > 1 ? WK : 0) * WN * 1024);       // FUSE: [WN][32][36] transpose tiles, then [32][WN][3]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int wk = w % WK, wn = w / WK;
-  const long long m0 = (long long)blockIdx.x * 32;
+  const long long m0 = (long long)blockIdx.x * ROWS;
   const int n0 = (blockIdx.y * WN + wn) * 32;
   ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 0);
 
@@ -325,9 +330,11 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
   const unsigned lane_off = (unsigned)(16 * h * p.ldn + colc);
   const int k_last = p.K - 1;
   struct Frag { float b[16]; } S0, S1, S2;
-  f32x16 acc;
+  f32x16 acc[RT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
   const float bias = p.bias ? p.bias[min(col, p.N - 1)] : 0.f;
 
   for (int kp0 = 0; kp0 < p.K; kp0 += kPanelMaxK) {  // one pass unless the input is wider than the panel (layer 0 only)
@@ -349,7 +356,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
 
     // ---- stage the panel: wave w takes rows w, w + NW, ...; lanes run along k (float4 each, coalesced)
     if (kp0 > 0) lds_barrier();  // the previous pass has been multiplied out
-    constexpr int RPW = (32 + NW - 1) / NW;            // rows per wave
+    constexpr int RPW = (ROWS + NW - 1) / NW;          // rows per wave
     // QMAX (template): float4 per lane and row the staging registers are sized for, 256 * QMAX >= min(K, panel)
     const int nq = (Kc + 255) >> 8;
     float4 gq[QMAX], bq[QMAX];                         // gamma / beta of this lane's columns, in flight with the rows
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
         for (int u = 0; u < 4; ++u) {
           rstd[u] = 1.f / sqrtf(wave_sum(m2[u]) / (float)Kc + p.eps);  // biased variance (keras LayerNormalization)
           const int row = w + (rr + u) * NW;
-          if (blockIdx.y == 0 && lane == 0 && row < 32 && m0 + row < p.M)
+          if (blockIdx.y == 0 && lane == 0 && row < ROWS && m0 + row < p.M)
             *reinterpret_cast<float2*>(p.stat_out + 2 * (m0 + row)) = make_float2(mean[u], rstd[u]);
         }
       }
@@ -433,7 +440,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int row = w + (rr + u) * NW;
-            if (row < 32 && k < PS - 4) {
+            if (row < ROWS && k < PS - 4) {
               float4 a, xh;  // (x - mean) * rstd * gamma + beta ; a zero feature row normalises to beta, 0 without LayerNorm
               const float rs = pad[u] ? 0.f : rstd[u], mu = pad[u] ? 0.f : mean[u];
               xh.x = k < Kc ? (xv[u][q].x - mu) * rs : 0.f;
@@ -456,14 +463,17 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
 
     auto compute = [&](Frag& S, int i) {
       const int kk = 32 * (c_begin + i) + 16 * h;
-      float a[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(s_panel + l31 * PS + kk + 4 * q);
-        a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+      for (int rt = 0; rt < RT; ++rt) {
+        float a[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(s_panel + (32 * rt + l31) * PS + kk + 4 * q);
+          a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], S.b[t], acc[rt], 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], S.b[t], acc, 0, 0, 0);
     };
 #define FWD_COMPUTE(S, i) compute(S, i)
     ULTR_STREAM_GEMM(nch, FWD_LOAD, FWD_COMPUTE);
@@ -475,11 +485,13 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
   // all waves of the workgroup share the activation math and the stores.
   constexpr int R = 16 / WK;
   float v[R];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {  // RT == 2: WK == 1 and no fused tail, the tiles go out one after the other
   if (WK > 1) {
     lds_barrier();  // every wave is done with the panel: the exchange buffer takes its place
     float* dst = s_acc + ((size_t)wk * WN + wn) * 1024 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[64 * r] = acc[r];
+    for (int r = 0; r < 16; ++r) dst[64 * r] = acc[rt][r];
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -490,7 +502,7 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < R; ++i) v[i] = acc[i];
+    for (int i = 0; i < R; ++i) v[i] = acc[rt][i];
   }
   // --- epilogue: bias + activation in the accumulator layout (one column per lane)
   switch (p.activation) {
@@ -507,10 +519,13 @@ __global__ void __launch_bounds__(64 * WN * WK, 2) fwd_layer_kernel(FwdArgs p) {
     if (col < p.ldn) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        const long long m = m0 + acc_row(wk * R + i, h);
+        const long long m = m0 + 32 * rt + acc_row(wk * R + i, h);
         if (m < p.M) p.act_out[m * p.ldn + col] = v[i];
       }
     }
+  }
+  }
+  if (!FUSE) {
     ULTR_STAMP((p.K == 512 ? 1 : p.K == 256 ? 2 : 0), 3);
     return;
   }
@@ -1917,12 +1932,12 @@ extern "C" int ultr_debug_stamps(long long* host, int n) {
 }
 #endif
 
-template <int WN, int WK, bool FUSE, bool GATHER, int QMAX>
+template <int WN, int WK, bool FUSE, bool GATHER, int QMAX, int RT = 1>
 static int launch_fwd_q(const FwdArgs& a, hipStream_t st, const char* name) {
-  const size_t smem = sizeof(float) * fwd_smem_floats<WN, WK>(a.K, FUSE);
+  const size_t smem = sizeof(float) * fwd_smem_floats<WN, WK, RT>(a.K, FUSE);
   static bool attr_set = false;  // the panel of a 512-wide layer is already past the 64 KB default
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX, RT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("ultr_dnn_forward: cannot raise the dynamic LDS limit");
       return ULTR_EHIP;
@@ -1931,17 +1946,26 @@ static int launch_fwd_q(const FwdArgs& a, hipStream_t st, const char* name) {
   }
   ULTR_REQUIRE(smem <= 160 * 1024, ULTR_ELIMIT, "ultr_dnn_forward: layer needs %zu bytes of LDS", smem);
   if (ultr::g_profile_on)  // name the instantiation and the GEMM shape the way rocprofv3 sees the kernel
-    name = ultr::profile_intern("%s<%d, %d, %s, %s, %d>/K%dN%d", name, WN, WK, FUSE ? "true" : "false", GATHER ? "true" : "false",
-                                QMAX, a.K, a.N);
+    name = ultr::profile_intern("%s<%d, %d, %s, %s, %d, %d>/K%dN%d", name, WN, WK, FUSE ? "true" : "false", GATHER ? "true" : "false",
+                                QMAX, RT, a.K, a.N);
   {
     ultr::ProfScope prof_(name, st);
-    hipLaunchKernelGGL((fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX>), dim3((unsigned)cdiv(a.M, 32), (unsigned)cdiv(a.N, 32 * WN)),
+    hipLaunchKernelGGL((fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX, RT>), dim3((unsigned)cdiv(a.M, 32 * RT), (unsigned)cdiv(a.N, 32 * WN)),
                        dim3(64 * WN * WK), smem, st, a);
   }
   return check_launch(name);
 }
+// ULTR_FWD_ROWTILES=1: one row tile per workgroup at every size
+static bool two_row_tiles(const FwdArgs& a, size_t smem_floats) {
+  static const bool on = [] { const char* e = getenv("ULTR_FWD_ROWTILES"); return !(e && e[0] == '1'); }();
+  return on && a.M >= 32768 && smem_floats * sizeof(float) <= 160 * 1024;
+}
 template <int WN, int WK, bool FUSE, bool GATHER>
 static int launch_fwd_g(const FwdArgs& a, hipStream_t st, const char* name) {
+  if constexpr (WK == 1 && !FUSE) {  // large batches: 64 rows per workgroup, two accumulator tiles per wave
+    if (two_row_tiles(a, fwd_smem_floats<WN, WK, 2>(a.K, FUSE)))
+      return a.K <= 512 ? launch_fwd_q<WN, WK, FUSE, GATHER, 2, 2>(a, st, name) : launch_fwd_q<WN, WK, FUSE, GATHER, 4, 2>(a, st, name);
+  }
   return a.K <= 512 ? launch_fwd_q<WN, WK, FUSE, GATHER, 2>(a, st, name) : launch_fwd_q<WN, WK, FUSE, GATHER, 4>(a, st, name);
 }
 template <int WN, int WK, bool FUSE>
