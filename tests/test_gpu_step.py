@@ -429,3 +429,39 @@ def test_online_simulation_feed_python_stream_and_training():
     assert (fb[DEVICE_BATCH_KEY].labels[:Ls].sum(0) >= 1).all()
     loss, _, _ = model.step(None, fb, False)
     assert np.isfinite(float(loss))
+
+
+@pytest.mark.parametrize('model_json', ['pbm_0.1_1.0_4_1.0.json', 'ubm_0.1_1_4_1.0.json', 'trust_bias.json'])
+def test_dynamic_bias_eta_schedule(model_json):
+    """dynamic_bias_eta_change / dynamic_bias_step_interval (click_simulation_feed.py:171-178): every `interval` batches
+    eta grows and setExamProb rebuilds the examination table from the BUILT-IN table ** eta (q5) -- the tables on the
+    device must follow, for every click-model kind, and the clicks sampled afterwards must come from the new tables."""
+    import json
+    from ultra_amd.utils import click_models as cm
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    path = os.path.join(os.path.dirname(PBM), model_json)
+    data = SyntheticData(200, 10, 12, seed=41)
+    exp = settings('DLA', feed_hparams='click_model_json=%s,dynamic_bias_eta_change=0.5,dynamic_bias_step_interval=2,'
+                                       'device_rng=False' % path)
+    model, feed = make('DLA', data, exp, 64)
+    ref = cm.loadModelFromJson(json.load(open(path)))
+    random.seed(5)
+    for batch_no in range(1, 5):
+        feed.get_batch(data, check_validation=True)
+        if batch_no % 2 == 0:
+            ref.eta += 0.5
+            ref.setExamProb(ref.eta)
+        want = ref.device_tables(10)[1]
+        assert feed.click_model.eta == ref.eta
+        assert feed.exam.cpu().tolist() == want, (model_json, batch_no)
+    assert feed.click_model.eta == 2.0
+    # a batch under the new tables, against the oracle on the same stream
+    g = {'model_name': ref.model_name, 'click_prob': ref.click_prob, 'exam_prob': ref.exam_prob, 'extra': getattr(ref, 'extra', None)}
+    random.seed(77)
+    feed_dict, info = feed.get_batch(data, check_validation=True)
+    random.seed(77)
+    u = [random.random() for _ in range(64 * 11 * 12)]
+    idxs, clicks, _ = O.get_batch_sequential(data.initial_list, data.labels, 10, 64, g['model_name'], g['click_prob'],
+                                             g['exam_prob'], u, True, g['extra'])
+    assert [x[0] for x in info['rank_list_idxs']] == idxs
+    assert np.array_equal(feed_dict[DEVICE_BATCH_KEY].labels.cpu().numpy().T, np.array(clicks, dtype=np.float32))
