@@ -169,3 +169,42 @@ def test_main_train_validate_checkpoint_and_test(tmp_path, capsys):
     from ultra_amd.utils import read_data
     test_set = read_data(flags.data_dir, 'test')
     assert len(scores) == len(test_set.initial_list) and len(lines) == sum(len(x) for x in test_set.initial_list)
+
+
+def test_dla_ndcg10_on_a_held_out_split_after_1000_steps():
+    """NDCG@10 on a held-out synthetic split after the fixed step count of the reference's MSLR pipeline
+    (1000, example/MSLR_WEB10k/offline_exp_pipeline.sh:79), against the op-for-op reference graph (float64) run from the
+    same initial weights on the same batches.  fp32 and float64 trajectories drift apart slowly over a thousand Adagrad
+    steps, so the bound here is on the metric (and on the loss of the last step), not on every parameter."""
+    import copy
+    import time
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    STEPS, B, F = 1000, 256, 136
+    data = SyntheticData(800, 10, F, seed=7)
+    rng = np.random.RandomState(7)
+    w = rng.normal(size=F) / np.sqrt(F)
+    rel = data.features[:-1] @ w * 3.0 + rng.normal(size=data.features.shape[0] - 1) * 0.3
+    cuts = np.quantile(rel, [0.52, 0.84, 0.97, 0.99])
+    data.labels = np.searchsorted(cuts, rel).astype(np.float32).reshape(800, 10)
+    train, held = copy.copy(data), copy.copy(data)
+    train.initial_list, train.labels, train.qids = data.initial_list[:600], data.labels[:600], data.qids[:600]
+    held.initial_list, held.labels, held.qids = data.initial_list[600:], data.labels[600:], data.qids[600:]
+    exp = settings('DLA', '', model_hparams='hidden_layer_sizes=[512, 256, 128]')
+    model, feed = make('DLA', train, exp, B)
+    pp = model.prop_params.cpu().numpy().astype(np.float64)
+    ref = reference_for('dla', model, 10, {}, with_metrics=False, prop_W=pp[:10, None], prop_b=pp[10:])
+    before, _ = _validate(model, held, exp, 200)
+    t0 = time.time()
+    for step in range(STEPS):
+        feed_dict, _ = feed.get_batch(train, True)
+        table, d, c = torch_feed(train, feed_dict[DEVICE_BATCH_KEY])
+        loss, _, _ = model.step(None, feed_dict, False)
+        ref_loss, _ = ref.step(table, d, c)
+    print('1000 steps on both sides: %.1f s' % (time.time() - t0))
+    assert abs(float(loss) - ref_loss) < 2e-3 * abs(ref_loss), (float(loss), ref_loss)
+    after, _ = _validate(model, held, exp, 200)
+    want = _reference_validation(ref, held.features, held.initial_list, held.labels)
+    print('held-out ndcg_10: before %.4f, after %.4f, reference %.4f' % (before['ndcg_10'], after['ndcg_10'], want['ndcg_10']))
+    assert after['ndcg_10'] > before['ndcg_10'] + 0.05                      # it learnt to rank unseen queries from clicks
+    assert abs(after['ndcg_10'] - want['ndcg_10']) < 2e-3, (after['ndcg_10'], want['ndcg_10'])
+    assert abs(after['ndcg_3'] - want['ndcg_3']) < 4e-3
