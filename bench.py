@@ -38,6 +38,9 @@ CONFIGS = {
     'yahoo': dict(F=700, L=10, Q=20000, algo='RegressionEM', click='pbm_0.1_1.0_4_1.0.json'),
     'istella': dict(F=220, L=10, Q=20000, algo='PairDebias', click='cascade_0.1_1.0_4_1.0.json'),
     'mslr30k': dict(F=136, L=10, Q=19000, algo='DLA', click='pbm_0.1_1.0_4_1.0.json'),
+    # BASELINE config 0: example/toy offline_exp_pipeline -- the reference's own CPU-runnable case, on its toy libsvm
+    # data (27 queries, lists of up to 9; tests/golden/toy_libsvm is a copy of example/toy/data)
+    'toy': dict(F=136, L=9, Q=27, algo='IPWrank', click='pbm_0.1_1.0_4_1.0.json', data_dir='toy_libsvm'),
 }
 HIDDEN = [512, 256, 128]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -78,7 +81,20 @@ def measured_traffic(kernel):
 def build_world(cfg, args, device):
     from ultra_amd.utils import find_class, metrics
     metrics.RankingMetricKey.MAX_LABEL = 4.0
-    data = SyntheticData(cfg['Q'], cfg['L'], cfg['F'], seed=1234, pad_frac=0.1)
+    if cfg.get('data_dir'):
+        from ultra_amd.utils import read_data
+        data = read_data(os.path.join(GOLDEN, cfg['data_dir']) + '/', 'train')
+        data.pad(data.rank_list_size)
+        metrics.RankingMetricKey.MAX_LABEL = 4.0
+        # the arrays the CPU restatement indexes
+        il = np.full((len(data.initial_list), cfg['L']), -1, dtype=np.int64)
+        lab = np.zeros((len(data.initial_list), cfg['L']), dtype=np.float32)
+        for i, (ids, labs) in enumerate(zip(data.initial_list, data.labels)):
+            il[i, :len(ids)] = ids
+            lab[i, :min(len(labs), cfg['L'])] = labs[:cfg['L']]
+        data.cpu_view = (np.asarray(data.features, dtype=np.float32), il, lab)
+    else:
+        data = SyntheticData(cfg['Q'], cfg['L'], cfg['F'], seed=1234, pad_frac=0.1)
     exp = {'ranking_model': 'ultra_amd.ranking_model.DNN',
            'ranking_model_hparams': 'hidden_layer_sizes=[512, 256, 128]',
            'learning_algorithm': 'ultra_amd.learning_algorithm.' + cfg['algo'],
@@ -111,8 +127,9 @@ def cpu_baseline(cfg, args, data, model):
         pp = model.prop_params.cpu().numpy()
         kw = dict(prop_W=pp[:cfg['L'], None], prop_b=pp[cfg['L']:])
     ref = TG.TorchReferenceStep(kind, ps, cfg['L'], {}, dtype=torch.float32, max_label=4.0, **kw)
-    features = [list(map(float, row)) for row in data.features]  # list of lists, like Raw_data.features
-    il, labels = data.initial_list.tolist(), data.labels.tolist()
+    feats_np, il_np, lab_np = getattr(data, 'cpu_view', (data.features, data.initial_list, data.labels))
+    features = [list(map(float, row)) for row in feats_np]  # list of lists, like Raw_data.features
+    il, labels = np.asarray(il_np).tolist(), np.asarray(lab_np).tolist()
     L, B = cfg['L'], args.batch
     ipw = json.load(open(os.path.join(GOLDEN, 'randomized_pbm_0.1_1.0_4_1.0.json')))['IPW_list']
     random.seed(1)
@@ -325,11 +342,11 @@ def main():
         else 'train query-lists/sec (%s)' % args.config,
         'value': round(value, 1), 'unit': 'query-lists/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 5), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not cfg.get('data_dir') else 'toy libsvm data of the reference (example/toy/data)',
         'config': {'workload': '%s shape: %d features, list %d, batch %d lists/GPU, DNN[512,256,128] + %s, %s clicks, '
-                               '%d synthetic queries resident in HBM' % (
+                               '%d %s queries resident in HBM' % (
                                    args.config, cfg['F'], cfg['L'], args.batch, cfg['algo'],
-                                   'PBM' if 'pbm' in cfg['click'] else 'cascade', cfg['Q']),
+                                   'PBM' if 'pbm' in cfg['click'] else 'cascade', cfg['Q'], 'toy-data' if cfg.get('data_dir') else 'synthetic'),
                    'global_batch': args.batch * world, 'list_size': cfg['L'], 'parallelism': 'dp%d' % world,
                    'launch': launch, 'feed_prefetch': bool(args.prefetch),
                    'train_gflop_per_step_per_gpu': round(train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9, 3)},

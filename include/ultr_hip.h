@@ -266,6 +266,12 @@ int ultr_loss_flush(void* stream);
  * supplied uniforms).  At most one request is parked per host thread; parking a second one launches the first. */
 int ultr_loss_ipw_deferred(const float* scores, const float* clicks, const float* pw, int B, int L, int loss_func,
                            float* d_scores, float* stats, float* list_weights, float* ws, void* stream);
+/* ultr_ipw_weights + ultr_loss_ipw_deferred in one request: the weights are formed from the clicks and the estimator's
+ * table (propensity_estimator.py:33-42) inside the carrying launch and also written to pw_out [L][B] (the
+ * propensity_weights{l} feed entries of ipw_rank.py:116-119, 214-223). */
+int ultr_loss_ipw_table_deferred(const float* scores, const float* clicks, const float* ipw, int n_ipw, float* pw_out,
+                                 int B, int L, int loss_func, float* d_scores, float* stats, float* list_weights,
+                                 float* ws, void* stream);
 int ultr_loss_pd_deferred(const float* scores, const float* clicks, int B, int L, const float* t_plus,
                           const float* t_minus, float* d_scores, float* stats, float* ws, void* stream);
 int ultr_loss_rem_deferred(const float* scores, const float* clicks, int B, int L, const float* propensity,

@@ -665,7 +665,7 @@ def test_dla_loss_rides_with_backward(L, F, hidden, B, Ls, loss_func, prob, maxw
             assert np.array_equal(a, b), (mode, name, np.abs(a - b).max())
 
 
-@pytest.mark.parametrize('kind', ['ipw', 'ipw_sigmoid', 'rem_uniforms', 'rem_philox', 'pd'])
+@pytest.mark.parametrize('kind', ['ipw', 'ipw_sigmoid', 'ipw_table', 'rem_uniforms', 'rem_philox', 'pd'])
 @pytest.mark.parametrize('F,hidden,B,Ls', [(136, [512, 256, 128], 256, 10), (46, [64, 32], 77, 16), (136, [], 40, 10)])
 def test_ipw_and_rem_losses_ride_with_backward(L, kind, F, hidden, B, Ls):
     """ultr_loss_ipw_deferred / ultr_loss_rem_deferred against a loss launch of its own followed by the same backward
@@ -689,8 +689,18 @@ def test_ipw_and_rem_losses_ride_with_backward(L, kind, F, hidden, B, Ls):
         grads = torch.full((model.n_total,), 7.0, dtype=torch.float32, device='cuda')
         ylab = torch.zeros((Ls, B), dtype=torch.float32, device='cuda')
         dbias = torch.zeros(1, dtype=torch.float32, device='cuda')
+        rng2 = np.random.RandomState(99)
         for _ in range(2):
-            if kind.startswith('ipw'):
+            if kind == 'ipw_table':  # weights from the estimator's table, formed inside the carrying launch
+                tab = dev(rng2.uniform(1.0, 9.0, size=max(Ls - 3, 1)), torch.float32)   # shorter than the list: last entry repeats
+                if ride:
+                    L.check(lib.ultr_loss_ipw_table_deferred(L.ptr(scores), L.ptr(clicks), L.ptr(tab), tab.numel(), L.ptr(ylab),
+                                                             B, Ls, 0, L.ptr(d), L.ptr(st), L.ptr(lw), L.ptr(ws), stream(L)), 'ipw')
+                else:
+                    L.check(lib.ultr_ipw_weights(L.ptr(clicks), B, Ls, L.ptr(tab), tab.numel(), L.ptr(ylab), stream(L)), 'w')
+                    L.check(lib.ultr_loss_ipw_fwdbwd(L.ptr(scores), L.ptr(clicks), L.ptr(ylab), B, Ls, 0, L.ptr(d), L.ptr(st),
+                                                     L.ptr(lw), L.ptr(ws), stream(L)), 'ipw')
+            elif kind.startswith('ipw'):
                 fn = lib.ultr_loss_ipw_deferred if ride else lib.ultr_loss_ipw_fwdbwd
                 L.check(fn(L.ptr(scores), L.ptr(clicks), L.ptr(pw), B, Ls, 1 if kind == 'ipw_sigmoid' else 0, L.ptr(d),
                            L.ptr(st), L.ptr(lw), L.ptr(ws), stream(L)), 'ipw')

@@ -4,6 +4,7 @@ set -e
 out=gpurun_out/configs
 mkdir -p $out
 run() { name=$1; shift; timeout -k 10 200 python bench.py --steps 100 --warmup 10 --cpu_seconds 4 "$@" > $out/$name.json 2> $out/$name.err; tail -1 $out/$name.json | cut -c1-400; }
+run c1_toy_ipw_b256 --config toy --batch 256
 run c2_mslr10k_b256 --config mslr10k --batch 256
 run c3_yahoo_b256 --config yahoo --batch 256
 run c4_istella_b256 --config istella --batch 256

@@ -83,6 +83,7 @@ SIGNATURES = {
     'ultr_loss_dla_deferred': (_I, [_P, _P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     'ultr_loss_flush': (_I, [_P]),
     'ultr_loss_ipw_deferred': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'ultr_loss_ipw_table_deferred': (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'ultr_loss_pd_deferred': (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     'ultr_loss_rem_deferred': (_I, [_P, _P, _I, _I, _P, _P, _P, _ULL, _U, _P, _U, _P, _P, _P, _P, _P, _P, _P]),
     'ultr_loss_rem_fwdbwd': (_I, [_P, _P, _I, _I, _P, _P, _P, _ULL, _U, _P, _U, _P, _P, _P, _P, _P, _P, _P]),

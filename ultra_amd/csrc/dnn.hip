@@ -1138,7 +1138,7 @@ __global__ void __launch_bounds__(kThreads) bwd_out_kernel(BwdOutArgs p) {
       const int r = lane & 15, lg = (int)(mg / p.ipw.B);
       const long long e = (long long)r * p.ipw.B + (mg - (long long)lg * p.ipw.B);
       const bool lv = r < p.ipw.L;
-      const float o = lv ? p.ipw.scores[e] : 0.f, c = lv ? p.ipw.clicks[e] : 0.f, wgt = lv ? p.ipw.pw[e] : 0.f;
+      const float o = lv ? p.ipw.scores[e] : 0.f, c = lv ? p.ipw.clicks[e] : 0.f, wgt = lv ? ipw_weight(p.ipw, e, r, c) : 0.f;
       const DlaLane v = dla_lane(o, c, wgt, lv, p.ipw.loss_func);
       go_group = group_sum<16>(r == lg ? v.ds : 0.f);
     }

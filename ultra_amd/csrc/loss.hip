@@ -492,7 +492,7 @@ static int ipw_args(const char* who, IpwArgs* a, const float* scores, const floa
   ULTR_REQUIRE(pw && d_scores && stats, ULTR_EINVAL, "%s: null pointer", who);
   ULTR_REQUIRE(loss_func == ULTR_LOSS_SOFTMAX || loss_func == ULTR_LOSS_SIGMOID, ULTR_EINVAL,
                "%s: loss_func=%d (pairwise_loss raises NameError in the reference and is not supported)", who, loss_func);
-  *a = IpwArgs{scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws};
+  *a = IpwArgs{scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws, nullptr, 0, nullptr};
   return ULTR_OK;
 }
 
@@ -525,6 +525,30 @@ extern "C" int ultr_loss_ipw_deferred(const float* scores, const float* clicks, 
   IpwArgs a;
   int rc = ipw_args("ultr_loss_ipw_deferred", &a, scores, clicks, pw, B, L, loss_func, d_scores, stats, list_weights, ws);
   if (rc) return rc;
+  rc = ultr_loss_flush(stream);
+  if (rc) return rc;
+  g_pending_loss.kind = ULTR_RIDE_IPW;
+  g_pending_loss.ipw = a;
+  g_pending_loss.nblocks = small_blocks(B);
+  return ULTR_OK;
+}
+
+extern "C" int ultr_ipw_weights(const float* clicks, int B, int L, const float* ipw, int n_ipw, float* pw, void* stream);
+
+extern "C" int ultr_loss_ipw_table_deferred(const float* scores, const float* clicks, const float* ipw, int n_ipw,
+                                            float* pw_out, int B, int L, int loss_func, float* d_scores, float* stats,
+                                            float* list_weights, float* ws, void* stream) {
+  ULTR_REQUIRE(ipw && n_ipw > 0 && pw_out, ULTR_EINVAL, "ultr_loss_ipw_table_deferred: needs the IPW table and pw_out");
+  if (L > 16) {  // long lists: the two launches of their own
+    int rc = ultr_ipw_weights(clicks, B, L, ipw, n_ipw, pw_out, stream);
+    if (rc) return rc;
+    return ultr_loss_ipw_fwdbwd(scores, clicks, pw_out, B, L, loss_func, d_scores, stats, list_weights, ws, stream);
+  }
+  IpwArgs a;
+  int rc = ipw_args("ultr_loss_ipw_table_deferred", &a, scores, clicks, pw_out, B, L, loss_func, d_scores, stats,
+                    list_weights, ws);
+  if (rc) return rc;
+  a.ipw_table = ipw; a.n_ipw = n_ipw; a.pw_out = pw_out;
   rc = ultr_loss_flush(stream);
   if (rc) return rc;
   g_pending_loss.kind = ULTR_RIDE_IPW;

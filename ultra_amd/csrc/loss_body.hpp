@@ -231,7 +231,15 @@ __device__ __forceinline__ void dla_loss_small_body(const DlaArgs& a, unsigned i
 struct IpwArgs {
   const float* scores; const float* clicks; const float* pw; int B, L, loss_func;
   float* d_scores; float* stats; float* list_weights; float* ws;
+  // ipw_table != NULL (ultr_loss_ipw_table_deferred): the weights are formed here from the clicks and the estimator's
+  // table (propensity_estimator.py:33-42) instead of being read from pw, and written to pw_out for whoever wants them
+  const float* ipw_table; int n_ipw; float* pw_out;
 };
+// weight of element (rank r, click c): supplied, or IPW_list[min(r, n - 1)] where clicked
+__device__ __forceinline__ float ipw_weight(const IpwArgs& a, long long e, int r, float c) {
+  if (!a.ipw_table) return a.pw[e];
+  return c > 0.f ? a.ipw_table[r < a.n_ipw ? r : a.n_ipw - 1] : 0.f;
+}
 
 __device__ __forceinline__ void ipw_loss_small_body(const IpwArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
                                                     float* s_part) {
@@ -244,8 +252,9 @@ __device__ __forceinline__ void ipw_loss_small_body(const IpwArgs& a, unsigned i
     const long long b = b0 + li;
     const bool live = in_list && b < B;
     const long long e = (long long)r * B + (b < B ? b : 0);
-    const float o = live ? a.scores[e] : 0.f, c = live ? a.clicks[e] : 0.f, w = live ? a.pw[e] : 0.f;
+    const float o = live ? a.scores[e] : 0.f, c = live ? a.clicks[e] : 0.f, w = live ? ipw_weight(a, e, r, c) : 0.f;
     if (live) wmax = fmaxf(wmax, w);
+    if (live && a.pw_out) a.pw_out[e] = w;
     const float lw = group_sum<16>(live ? w * fminf(fmaxf(c, 0.f), 1.f) : 0.f);
     const DlaLane v = dla_lane(o, c, w, live, loss_func);
     if (live) {

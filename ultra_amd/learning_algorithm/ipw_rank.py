@@ -45,10 +45,15 @@ class IPWrank(BaseAlgorithm):
         if self._pw is None or self._pw.shape[1] != batch.B:
             self._pw = torch.empty((L, batch.B), dtype=torch.float32, device=self.device)
         # propensity_weights placeholders filled per list (ipw_rank.py:214-223)
+        if self._loss_rides():  # weights and loss in one parked request, carried by the backward pass's first launch
+            _lib.check(_lib.lib().ultr_loss_ipw_table_deferred(
+                _lib.ptr(scores), _lib.ptr(batch.labels), _lib.ptr(self.ipw_table), L, _lib.ptr(self._pw), batch.B, L,
+                self.loss_kind, _lib.ptr(tb['d_scores']), _lib.ptr(tb['stats']), _lib.ptr(tb['list_weights']),
+                _lib.ptr(tb['loss_ws']), _lib.current_stream()), 'ultr_loss_ipw_table_deferred')
+            return
         _lib.check(_lib.lib().ultr_ipw_weights(_lib.ptr(batch.labels), batch.B, L, _lib.ptr(self.ipw_table), L,
                                                _lib.ptr(self._pw), _lib.current_stream()), 'ultr_ipw_weights')
-        fn = _lib.lib().ultr_loss_ipw_deferred if self._loss_rides() else _lib.lib().ultr_loss_ipw_fwdbwd
-        _lib.check(fn(
+        _lib.check(_lib.lib().ultr_loss_ipw_fwdbwd(
             _lib.ptr(scores), _lib.ptr(batch.labels), _lib.ptr(self._pw), batch.B, L, self.loss_kind,
             _lib.ptr(tb['d_scores']), _lib.ptr(tb['stats']), _lib.ptr(tb['list_weights']), _lib.ptr(tb['loss_ws']),
             _lib.current_stream()), 'ultr_loss_ipw_fwdbwd')
