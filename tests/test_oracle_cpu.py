@@ -409,3 +409,33 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(src), os.path.join(dirpath, f)
                 assert 'ultr_oracle' not in src and 'torch_graph' not in src, os.path.join(dirpath, f)
+
+
+def test_main_flags_and_checkpoint_index(tmp_path):
+    """ultra_amd.main without a GPU: the reference's flag names and defaults (main.py:24-51), the mapping of the reference's
+    own `ultra.*` class names onto the drop-in classes, and the checkpoint index that stands in for
+    tf.train.get_checkpoint_state (main.py:68-74)."""
+    import json
+    from ultra_amd import main as M
+    f = M.Flags(batch_size=32, test_only=True)
+    assert (f.batch_size, f.test_only, f.steps_per_checkpoint, f.selection_bias_cutoff, f.max_train_iteration) == \
+        (32, True, 50, 10, 10000)
+    assert f.data_dir == './tests/data/' and f.train_data_prefix == 'train' and f.max_list_cutoff == 0
+    with pytest.raises(AttributeError):
+        M.Flags(no_such_flag=1)
+    assert M._drop_in('ultra.learning_algorithm.DLA') == 'ultra_amd.learning_algorithm.DLA'
+    assert M._drop_in('my_pkg.MyAlgo') == 'my_pkg.MyAlgo'
+    assert M._checkpoint_state(str(tmp_path)) is None
+    ckpt = str(tmp_path / 'ultra.learning_algorithm.DLA.ckpt-50')
+    json.dump({'model_checkpoint_path': ckpt}, open(str(tmp_path / 'checkpoint'), 'w'))
+    assert M._checkpoint_state(str(tmp_path)) is None          # the index names a file that is not there
+    open(ckpt + '.pt', 'wb').close()
+    assert M._checkpoint_state(str(tmp_path)) == ckpt
+    # every feed / algorithm / ranker the reference's example settings name resolves to a drop-in class by dotted name
+    from ultra_amd.utils import find_class
+    for name in ('ultra.input_layer.ClickSimulationFeed', 'ultra.input_layer.DirectLabelFeed',
+                 'ultra.input_layer.DeterministicOnlineSimulationFeed', 'ultra.input_layer.StochasticOnlineSimulationFeed',
+                 'ultra.learning_algorithm.DLA', 'ultra.learning_algorithm.IPWrank', 'ultra.learning_algorithm.RegressionEM',
+                 'ultra.learning_algorithm.PairDebias', 'ultra.learning_algorithm.NavieAlgorithm',
+                 'ultra.ranking_model.DNN', 'ultra.ranking_model.Linear'):
+        assert find_class(M._drop_in(name)).__name__ == name.rsplit('.', 1)[1]
