@@ -7,6 +7,7 @@ reported from a large-batch run).  Algorithmic bytes per unit are SURVEY 8d's:
   click        8 L B per candidate list (read labels fp32, write clicks)
   DLA loss     12 L B per list (read scores and clicks, write d_scores)
   metrics      8 L B per list (read scores and labels) + 4 B per metric
+  online feed  20 Lmax B per list (doc ids, labels, scores in; doc ids, clicks out)
   optimiser    20 B per parameter (read g, acc, theta; write acc, theta) + 8 B for the norm pass
 
     python tools/bench_hbm_kernels.py > profiles/r01_hbm_kernels.txt      (on the GPU box)
@@ -79,6 +80,13 @@ def main():
         docids = torch.zeros((Ls, B), dtype=torch.int32, device=dev)
         report('metrics mrr+ndcg@3,5,10', B, 'lists', (8 + 4) * Ls * B + 4 * plan.n_out, timed(
             lambda: M.batch_metrics(plan, scores, lab_lb, docids, 10, lw, out, mws, None, max_label=4.0)))
+        # online simulation: re-rank by score + click model, one workgroup per list (20 Lmax bytes per list: doc ids,
+        # labels and scores in, doc ids and clicks out)
+        dl = torch.randint(0, 1000, (Ls, B), device=dev, dtype=torch.int32)
+        od, oc = torch.empty_like(dl), torch.empty_like(lab_lb)
+        report('online rerank + click', B, 'lists', 20 * Ls * B, timed(lambda: L.check(lib.ultr_online_rerank_click(
+            L.ptr(dl), L.ptr(lab_lb), L.ptr(scores), B, Ls, Ls, 1000, 0, L.ptr(exam), exam.numel(), L.ptr(cp), cp.numel(), None,
+            2024, 1, None, 0, 1, 100, L.ptr(od), L.ptr(oc), None, st), 'online')))
     for n in (236608, 1 << 22, 1 << 26):
         th, ac, gr = torch.randn(n, device=dev), torch.full((n,), 0.1, device=dev), torch.randn(n, device=dev) * 1e-3
         dn = torch.ones(1, device=dev)
