@@ -765,7 +765,8 @@ def test_alternate_kernel_paths_in_a_fresh_process(env):
 # online simulation: re-rank by score + click model
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('model_file,B,Lmax,Ls', [('pbm_0.1_1.0_4_1.0.json', 200, 12, 10), ('cascade_0.1_1.0_4_1.0.json', 64, 9, 9),
-                                                  ('ubm_0.1_1_4_1.0.json', 100, 30, 10), ('trust_bias.json', 50, 300, 10),
+                                                  ('ubm_0.1_1_4_1.0.json', 100, 30, 10), ('ubm_0.1_1_4_1.0.json', 70, 14, 10), ('trust_bias.json', 50, 300, 10),
+                                                  ('trust_bias.json', 33, 16, 16),
                                                   ('oracle', 40, 12, 5)])
 def test_online_rerank_click_kernel(L, model_file, B, Lmax, Ls):
     """ultr_online_rerank_click against the reference's per-list loop (deterministic_online_simulation_feed.py:129-187):
@@ -858,3 +859,37 @@ def test_online_sample_click_kernel_plackett_luce(L):
     freq = np.bincount(firsts[0], minlength=4) / n
     assert np.abs(freq - p).max() < 4 * np.sqrt(0.25 / n), (freq, p)
     assert (firsts[0] != firsts[1]).mean() > 0.3
+
+
+@pytest.mark.parametrize('model_file,stochastic', [('pbm_0.1_1.0_4_1.0.json', False), ('ubm_0.1_1_4_1.0.json', False),
+                                                   ('cascade_0.1_1.0_4_1.0.json', True)])
+def test_online_kernels_short_and_long_list_layouts_agree(L, model_file, stochastic):
+    """Lists of at most 16 candidates take the 16-lanes-per-list kernel, longer ones a workgroup per list.  The same
+    lists with one more (padding) column go through the other kernel and must come out identical: same ranking, same
+    Philox draws for the Plackett-Luce noise and for every re-sampling round of the clicks."""
+    model = load_json(model_file)
+    rng = np.random.RandomState(17)
+    B, Lmax, Ls, n_rows = 333, 16, 10, 4000
+    lens = rng.randint(0, Lmax + 1, size=B)
+    docids = np.full((B, Lmax + 1), n_rows, dtype=np.int32)
+    labels = np.zeros((B, Lmax + 1), dtype=np.float32)
+    for i in range(B):
+        docids[i, :lens[i]] = rng.choice(n_rows, size=lens[i], replace=False)
+        labels[i, :lens[i]] = rng.choice(5, size=lens[i])
+    scores = np.round(rng.normal(size=(B, Lmax + 1)), 1).astype(np.float32)
+    kind, exam, n_exam, cp = _device_click_model(model, Ls)
+    outs = []
+    for width in (Lmax, Lmax + 1):
+        o = [torch.full((width, B), -5, dtype=t, device='cuda') for t in (torch.int32, torch.float32, torch.int32)]
+        args = (L.ptr(dev(docids[:, :width].T)), L.ptr(dev(labels[:, :width].T)), L.ptr(dev(scores[:, :width].T)), B, width, Ls,
+                n_rows, kind, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), None, 4242, 3, None, 1000, 1, 100, L.ptr(o[0]),
+                L.ptr(o[1]), L.ptr(o[2]), stream(L))
+        if stochastic:
+            L.check(L.lib().ultr_online_sample_click(1.5, None, *args), 'online')
+        else:
+            L.check(L.lib().ultr_online_rerank_click(*args), 'online')
+        outs.append([t.cpu().numpy()[:Lmax] for t in o])
+    for a, b, name in zip(outs[0], outs[1], ('docids', 'clicks', 'order')):
+        assert np.array_equal(a, b), name
+    shown = np.minimum(lens, Ls) > 0
+    assert (outs[0][1][:Ls].sum(0)[shown] >= 1).all()

@@ -265,6 +265,96 @@ __global__ void __launch_bounds__(256) online_rerank_click_kernel(OnlineArgs a) 
   if (live) a.out_clicks[(long long)lane * B + b] = ((mask >> lane) & 1ull) ? 1.f : 0.f;
 }
 
+
+// The same for short lists (Lmax <= 16): 16 lanes per list, four lists per wave, sixteen per workgroup -- the list
+// lives in registers, ranks come from 16 group shuffles, and every group re-samples its clicks on its own (the wave
+// loops until its last list is done).  Same draws and results as online_rerank_click_kernel.
+__global__ void __launch_bounds__(256) online_rerank_click_small_kernel(OnlineArgs a) {
+  const int Lmax = a.Lmax, B = a.B, tid = threadIdx.x, lane = tid & 63;
+  const int r = lane & 15, gbase = lane & 48;
+  const long long b = (long long)blockIdx.x * 16 + (tid >> 4);
+  const bool in_batch = b < B, has_pos = in_batch && r < Lmax;
+  const long long e = (long long)r * B + (in_batch ? b : 0);
+  const int doc = has_pos ? a.docids[e] : a.n_rows;
+  const float lab = has_pos ? a.labels[e] : 0.f;
+  double key = has_pos ? (double)a.scores[e] : 0.0;
+  const unsigned int step = a.step + (a.step_ctr ? *a.step_ctr : 0u);
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32), slot = a.slot_base + (uint32_t)b;
+  if (a.stochastic && has_pos) {
+    double u;
+    if (a.rank_uniforms) {
+      u = a.rank_uniforms[b * Lmax + r];
+    } else {
+      const Philox4 bd = philox4x32_10(slot, 0xFFFFFFFFu, (uint32_t)(r >> 1), step, k0, k1);
+      u = (r & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+    }
+    u = u > 8.673617379884035e-19 ? u : 8.673617379884035e-19;
+    key = (double)a.tau * key - log(-log(u));
+  }
+  const int len = (int)group_max<16>(has_pos && doc < a.n_rows ? (float)(r + 1) : 0.f);
+  // rank of position r among the positions < len, then the position that lands on rank r
+  int rank = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const double kq = __shfl(key, gbase + q, 64);
+    rank += (q < len && (kq > key || (kq == key && q < r))) ? 1 : 0;
+  }
+  int src = r;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rq = __shfl(rank, gbase + q, 64);
+    if (r < len && q < len && rq == r) src = q;
+  }
+  const int rdoc = __shfl(doc, gbase + src, 64);
+  const float rlab = __shfl(lab, gbase + src, 64);
+  if (has_pos) {
+    a.out_docids[e] = rdoc;
+    if (a.out_perm) a.out_perm[e] = src;
+  }
+  const int Lc = a.L < len ? a.L : len;
+  const bool live = has_pos && r < Lc;
+  float click = 0.f;
+  if (a.click_model == ULTR_CLICK_ORACLE) {
+    click = live ? rlab : 0.f;
+  } else {
+    const int rounds = a.uniforms ? 1 : 1 + (a.check_validation ? a.max_rounds : 0);
+    bool done = !in_batch || Lc == 0;
+    unsigned int mask = 0u;
+    for (int round = 0; round < rounds; ++round) {
+      if (__ballot(!done) == 0ull) break;
+      double u = 2.0;
+      if (live && !done) {
+        if (a.uniforms) {
+          u = a.uniforms[b * a.L + r];
+        } else {
+          const Philox4 bd = philox4x32_10(slot, (uint32_t)round, (uint32_t)(r >> 1), step, k0, k1);
+          u = (r & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+        }
+      }
+      bool c = false;
+      if (a.click_model == ULTR_CLICK_UBM) {
+        int last_click = -1;
+        for (int q = 0; q < 16; ++q) {  // wave-uniform bound: the ranks of every list resolve in order
+          const bool cq = live && !done && r == q && u < click_threshold(a.t, a.click_model, r, rlab, last_click);
+          const unsigned long long bq = __ballot(cq);
+          if ((bq >> (gbase + q)) & 1ull) last_click = q;
+          c = c || cq;
+        }
+      } else {
+        c = live && !done && u < click_threshold(a.t, a.click_model, r, rlab, -1);
+      }
+      unsigned int m = (unsigned int)((__ballot(c) >> gbase) & 0xFFFFull);
+      if (a.click_model == ULTR_CLICK_CASCADE) m &= (~m + 1u);  // only the first click counts
+      if (!done) {
+        mask = m;
+        if (m != 0u || !a.check_validation) done = true;
+      }
+    }
+    click = live && ((mask >> r) & 1u) ? 1.f : 0.f;
+  }
+  if (has_pos) a.out_clicks[e] = r < len ? click : lab;  // ranks beyond the shown ones are 0, padding keeps its label
+}
+
 }  // namespace ultr
 
 using namespace ultr;
@@ -448,6 +538,11 @@ static int online_common(int stochastic, float tau, const double* rank_uniforms,
   a.check_validation = check_validation; a.max_rounds = max_rounds;
   a.out_docids = out_docids; a.out_clicks = out_clicks; a.out_perm = out_perm;
   a.stochastic = stochastic; a.tau = tau; a.rank_uniforms = rank_uniforms;
+  if (Lmax <= 16) {  // short lists: sixteen lanes per list
+    ultr::ProfScope prof_("online_rerank_click_kernel", as_stream(stream));
+    hipLaunchKernelGGL(online_rerank_click_small_kernel, dim3((unsigned)cdiv(B, 16)), dim3(256), 0, as_stream(stream), a);
+    return check_launch("online_rerank_click_small_kernel");
+  }
   {
     ultr::ProfScope prof_("online_rerank_click_kernel", as_stream(stream));
     hipLaunchKernelGGL(online_rerank_click_kernel, dim3((unsigned)B), dim3(256),
