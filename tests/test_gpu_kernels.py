@@ -91,6 +91,31 @@ def test_click_kernels_bit_exact_on_reference_goldens(L):
                 assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize('model_file', ['pbm_0.1_1.0_4_1.0.json', 'cascade_0.1_1.0_4_1.0.json', 'ubm_0.1_1_4_1.0.json'])
+def test_click_kernel_long_lists(L, model_file):
+    """Lists longer than 16 take the thread-per-list kernel (shorter ones the lane-per-element one): supplied uniforms
+    against the oracle, and the Philox stream of a long list against its restatement."""
+    g = load_json(model_file)
+    rng = np.random.RandomState(29)
+    n, Ls = 1500, 24
+    labels = rng.choice(6, size=(n, Ls)).astype(np.float32)
+    u = rng.random_sample((n, Ls)) * 0.8
+    kind, exam, n_exam, cp = _device_click_model(g, Ls)
+    out = torch.empty((n, Ls), dtype=torch.float32, device='cuda')
+    L.check(L.lib().ultr_click_sample(kind, L.ptr(dev(labels)), n, Ls, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(),
+                                      L.ptr(dev(u)), 0, 0, L.ptr(out), stream(L)), 'click')
+    want = np.array([O.sample_clicks_one_list(g['model_name'], g['click_prob'], g['exam_prob'], list(labels[i]), u[i])
+                     for i in range(n)], dtype=np.float32)
+    assert np.array_equal(out.cpu().numpy(), want)
+    L.check(L.lib().ultr_click_sample(kind, L.ptr(dev(labels)), n, Ls, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), None,
+                                      0xFEED, 2, L.ptr(out), stream(L)), 'click')
+    got = out.cpu().numpy()
+    for i in (0, 7, n - 1):
+        ui = O.philox_uniforms(0xFEED, 2, i, 0, Ls)
+        assert got[i].tolist() == [float(c) for c in O.sample_clicks_one_list(
+            g['model_name'], g['click_prob'], g['exam_prob'], list(labels[i]), ui)]
+
+
 @pytest.mark.parametrize('model_file', ['ubm_0.1_1_4_1.0.json', 'trust_bias.json', 'click_matrix_tiangong.json'])
 def test_click_kernel_bulk_other_models(L, model_file):
     g = load_json(model_file)

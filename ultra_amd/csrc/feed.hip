@@ -46,6 +46,47 @@ __global__ void __launch_bounds__(256) click_kernel(int model, const float* __re
   }
 }
 
+// Short lists (L <= 16): one lane per (list, rank), sixteen lanes per list, so that a wave reads four whole lists
+// with one coalesced load and every lane evaluates one Philox block and one float64 threshold instead of L of them.
+// Same draws as click_kernel (draw r of the stream (list, 0, *, step): words (2r, 2r+1) of its block sequence).
+__global__ void __launch_bounds__(256) click_small_kernel(int model, const float* __restrict__ labels, long long n, int L,
+                                                          ClickTables t, const double* __restrict__ uniforms,
+                                                          unsigned long long seed, unsigned int step,
+                                                          float* __restrict__ clicks) {
+  const int lane = threadIdx.x & 63, r = lane & 15, gbase = lane & 48;
+  const long long nblk = ((long long)n + 15) / 16;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long i = blk * 16 + (threadIdx.x >> 4);
+    const bool live = i < n && r < L;
+    const float lab = live ? labels[i * L + r] : 0.f;
+    double u = 2.0;
+    if (live) {
+      if (uniforms) {
+        u = uniforms[i * L + r];
+      } else {
+        const Philox4 bd = philox4x32_10((uint32_t)i, 0u, (uint32_t)(r >> 1), step, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u = (r & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+      }
+    }
+    bool c = false;
+    if (model == ULTR_CLICK_UBM) {
+      int last = -1;
+      for (int q = 0; q < L; ++q) {  // the ranks of a list resolve in order: each needs the last click above it
+        const bool cq = live && r == q && u < click_threshold(t, model, r, lab, last);
+        if ((__ballot(cq) >> (gbase + q)) & 1ull) last = q;
+        c = c || cq;
+      }
+    } else {
+      c = live && u < click_threshold(t, model, r, lab, -1);
+    }
+    if (model == ULTR_CLICK_CASCADE) {  // only the first click of the list is kept (a draw was made at every rank)
+      const unsigned int m = (unsigned int)((__ballot(c) >> gbase) & 0xFFFFull);
+      c = c && (m & ((1u << r) - 1u)) == 0u;
+    }
+    if (live) clicks[i * L + r] = c ? 1.f : 0.f;
+  }
+}
+
 // Evaluate one candidate: pick the list, sample its clicks.  Returns the click bit mask.
 template <typename DrawFn>
 __device__ __forceinline__ unsigned long long eval_candidate(DrawFn&& draw, const int* __restrict__ initial_list,
@@ -380,6 +421,13 @@ extern "C" int ultr_click_sample(int click_model, const float* labels, long long
   ULTR_REQUIRE(n < (1ll << 32), ULTR_ELIMIT, "ultr_click_sample: n=%lld exceeds the 32-bit Philox list counter", n);
   if (n == 0) return ULTR_OK;
   ClickTables t{exam, n_exam, click_prob, n_click_prob};
+  if (L <= 16) {
+    const long long blocks = cdiv(n, 16) < 65536 ? cdiv(n, 16) : 65536;  // capped grid, block-strided beyond
+    ultr::ProfScope prof_("click_kernel", as_stream(stream));
+    hipLaunchKernelGGL(click_small_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), click_model, labels, n,
+                       L, t, uniforms, seed, stream_step, clicks);
+    return check_launch("click_small_kernel");
+  }
   {
     ultr::ProfScope prof_("click_kernel", as_stream(stream));
     hipLaunchKernelGGL(click_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), click_model, labels, n,
