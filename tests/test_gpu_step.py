@@ -465,3 +465,41 @@ def test_dynamic_bias_eta_schedule(model_json):
                                              g['exam_prob'], u, True, g['extra'])
     assert [x[0] for x in info['rank_list_idxs']] == idxs
     assert np.array_equal(feed_dict[DEVICE_BATCH_KEY].labels.cpu().numpy().T, np.array(clicks, dtype=np.float32))
+
+
+@pytest.mark.parametrize('algo', ['DLA', 'RegressionEM', 'PairDebias'])
+def test_hipgraph_replay_equals_eager_steps(algo):
+    """bench.py times the whole step (prefetching feed + forward + riding loss + backward + riding metrics and assembly +
+    fused tail) as ONE captured hipGraph.  Replaying that graph N times must leave exactly the parameters, optimiser state
+    and loss that N eager steps leave: the Philox step counter lives on the device, so every replay draws a fresh batch."""
+    data = SyntheticData(300, 10, 24, seed=13, pad_frac=0.1)
+    results = []
+    for use_graph in (False, True):
+        exp = settings(algo, feed_hparams='click_model_json=%s,seed=11,prefetch=true' % PBM)
+        model, feed = make(algo, data, exp, 128)
+
+        def step():
+            input_feed, _ = feed.get_batch(data, check_validation=True)
+            return model.step(None, input_feed, False)
+        for _ in range(2):
+            last = step()
+        if use_graph:
+            model.enable_graph_replay(True)
+            last = step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                last = step()                       # recorded, not executed
+            for _ in range(4):
+                graph.replay()
+        else:
+            for _ in range(5):
+                last = step()
+        torch.cuda.synchronize()
+        extra = {'DLA': lambda: model.prop_params, 'RegressionEM': lambda: model.propensity,
+                 'PairDebias': lambda: model.t_plus}[algo]().clone()
+        results.append((model.model.params.clone(), model.acc.clone(), extra, float(last[0])))
+        del feed
+    (p0, a0, e0, l0), (p1, a1, e1, l1) = results
+    assert torch.equal(p0, p1) and torch.equal(a0, a1) and torch.equal(e0, e1)
+    assert l0 == l1 and np.isfinite(l0)

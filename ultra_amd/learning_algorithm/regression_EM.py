@@ -49,7 +49,10 @@ class RegressionEM(BaseAlgorithm):
         fn = _lib.lib().ultr_loss_rem_deferred if self._loss_rides() else _lib.lib().ultr_loss_rem_fwdbwd
         _lib.check(fn(
             _lib.ptr(scores), _lib.ptr(batch.labels), batch.B, L, _lib.ptr(self.propensity),
-            _lib.ptr(self.sigmoid_prob_b), _lib.ptr(self.uniforms), self.seed, self.global_step.value & 0xFFFFFFFF,
+            # the Bernoulli draws are keyed by the device step counter the feed advances (fresh draws on every replay
+            # of a captured step, the same ones an eager step makes); the host step count only without such a feed
+            _lib.ptr(self.sigmoid_prob_b), _lib.ptr(self.uniforms), self.seed,
+            0 if self.step_ctr is not None else self.global_step.value & 0xFFFFFFFF,
             _lib.ptr(self.step_ctr), self.rank * batch.B, _lib.ptr(tb['d_scores']), None,
             _lib.ptr(tb['list_weights']), _lib.ptr(tb['stats']), _lib.ptr(tb['grads'][self.n_params:]),
             _lib.ptr(tb['loss_ws']), _lib.current_stream()), 'ultr_loss_rem_fwdbwd')
