@@ -474,7 +474,7 @@ def test_hipgraph_replay_equals_eager_steps(algo):
     and loss that N eager steps leave: the Philox step counter lives on the device, so every replay draws a fresh batch."""
     data = SyntheticData(300, 10, 24, seed=13, pad_frac=0.1)
     results = []
-    for use_graph in (False, True):
+    for use_graph in (False, True, 'split'):
         exp = settings(algo, feed_hparams='click_model_json=%s,seed=11,prefetch=true' % PBM)
         model, feed = make(algo, data, exp, 128)
 
@@ -483,7 +483,23 @@ def test_hipgraph_replay_equals_eager_steps(algo):
             return model.step(None, input_feed, False)
         for _ in range(2):
             last = step()
-        if use_graph:
+        if use_graph == 'split':
+            # the data-parallel launch path of bench.py: one graph up to the collective, one after it (the all-reduce
+            # itself, a no-op on one rank, is issued between the two replays)
+            model.enable_graph_replay(True)
+            last = step()
+            torch.cuda.synchronize()
+            g_local, g_apply = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_local):
+                input_feed, _ = feed.get_batch(data, check_validation=True)
+                model.step_local(input_feed)
+            with torch.cuda.graph(g_apply):
+                last = model.step_apply()
+            for _ in range(4):
+                g_local.replay()
+                model.step_reduce()
+                g_apply.replay()
+        elif use_graph:
             model.enable_graph_replay(True)
             last = step()
             torch.cuda.synchronize()
@@ -500,6 +516,7 @@ def test_hipgraph_replay_equals_eager_steps(algo):
                  'PairDebias': lambda: model.t_plus}[algo]().clone()
         results.append((model.model.params.clone(), model.acc.clone(), extra, float(last[0])))
         del feed
-    (p0, a0, e0, l0), (p1, a1, e1, l1) = results
-    assert torch.equal(p0, p1) and torch.equal(a0, a1) and torch.equal(e0, e1)
-    assert l0 == l1 and np.isfinite(l0)
+    p0, a0, e0, l0 = results[0]
+    for p1, a1, e1, l1 in results[1:]:
+        assert torch.equal(p0, p1) and torch.equal(a0, a1) and torch.equal(e0, e1)
+        assert l0 == l1 and np.isfinite(l0)
