@@ -214,6 +214,25 @@ int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const 
                             const float* table_stats, int n_rows, int ldx, const int* docids, long long M,
                             void* workspace, const float* d_scores, float* grads, float* sumsq, void* stream);
 
+/* The fused training step for short lists (L <= 16): one call in place of ultr_dnn_forward + the loss + ultr_dnn_backward
+ * (the reference runs all of them in ONE session.run: DNN.py:63-96, dla.py:119-180 + 237-239 and the other algorithms'
+ * graphs).  A workgroup owns whole lists and carries them through forward, d_score, and the dgrad / LayerNorm-backward
+ * chain with every activation in LDS; one launch then forms every layer's weight gradient, one reduces the partials.
+ *   The loss comes from the request parked by ultr_loss_{dla,ipw,ipw_table,rem,pd}_deferred on this host thread: its
+ *   `scores` must be this call's `scores` and its B, L this call's (ULTR_EINVAL otherwise; the request is consumed).
+ *   The chain kernel evaluates d_score with the loss kernels' own lane functions (same bits) and writes scores and the
+ *   list weights; the request's statistics (and d_scores, prop_grads, pw_out) are produced by rider workgroups of the
+ *   weight-gradient launch.  A parked ultr_metrics_deferred request rides there too, a parked
+ *   ultr_batch_assemble_deferred request with the last launch.
+ *   grads[0..n_params) and sumsq (may be NULL) as ultr_dnn_backward_sumsq.  docids [L][B] position-major.
+ * ultr_dnn_fused_workspace_bytes: bytes of workspace for (B, L); 0 when the shape is not supported (no hidden layer,
+ * L > 16, widths whose 16-row panels do not fit the 160 KB of LDS) -- use the separate entry points then; -1 on a bad
+ * descriptor. */
+long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int B, int L);
+int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params, const float* table,
+                         const float* table_stats, int n_rows, int ldx, const int* docids, int B, int L,
+                         void* workspace, float* scores, float* grads, float* sumsq, void* stream);
+
 /* ---- losses, forward + backward in one pass -------------------------------------------
  * All take scores/clicks position-major [L][B] and write d_scores [L][B] UN-NORMALISED: the
  * caller's optimiser call divides by the batch-global normaliser in `stats` (this is what
@@ -260,6 +279,8 @@ int ultr_loss_dla_deferred(const float* scores, const float* clicks, int B, int 
                            int loss_func, int logits_to_prob, float max_propensity_weight, float* d_scores,
                            float* prop_grads, float* list_weights, float* stats, float* ws, void* stream);
 int ultr_loss_flush(void* stream);
+/* Drop a parked loss request without running it; returns 1 if there was one. */
+int ultr_loss_cancel(void);
 /* The same for the IPW / naive loss (ultr_loss_ipw_fwdbwd: pw must be ready when the backward pass runs), the pairwise
  * debiasing loss (ultr_loss_pd_fwdbwd) and the regression-EM loss (ultr_loss_rem_fwdbwd: its d_score is elementwise, sigmoid(score + b) - Bernoulli label, so the
  * backward workgroups draw the label of each of their rows themselves, from the same Philox counter or the same
@@ -333,6 +354,8 @@ int ultr_metrics_deferred(const float* scores, const float* labels, const int* d
                  const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
                  int n_topn, int metric_mask, float max_label, float* out, float* ws, void* stream);
 int ultr_metrics_flush(void* stream);
+/* Drop a parked request without running it (the scores it describes never came to be); returns 1 if there was one. */
+int ultr_metrics_cancel(void);
 /* The permutation itself: perm [B][topn] int32 = sort_by_scores(scores) indices. */
 int ultr_sort_by_scores(const float* scores, const float* u, int B, int Lx, int topn, int* perm,
                         void* stream);

@@ -76,12 +76,15 @@ SIGNATURES = {
     'ultr_dnn_backward': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P, _P]),
     'ultr_dnn_backward_sumsq': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _LL, _P, _P, _P, _P, _P]),
     'ultr_dnn_sumsq_count': (_I, [_DESC]),
+    'ultr_dnn_fused_workspace_bytes': (_LL, [_DESC, _I, _I]),
+    'ultr_dnn_train_fused': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     'ultr_loss_workspace_floats': (_LL, [_I, _I]),
     'ultr_loss_ipw_fwdbwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'ultr_ipw_weights': (_I, [_P, _I, _I, _P, _I, _P, _P]),
     'ultr_loss_dla_fwdbwd': (_I, [_P, _P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     'ultr_loss_dla_deferred': (_I, [_P, _P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     'ultr_loss_flush': (_I, [_P]),
+    'ultr_loss_cancel': (_I, []),
     'ultr_loss_ipw_deferred': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'ultr_loss_ipw_table_deferred': (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'ultr_loss_pd_deferred': (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -94,6 +97,7 @@ SIGNATURES = {
     'ultr_metrics': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
     'ultr_metrics_deferred': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
     'ultr_metrics_flush': (_I, [_P]),
+    'ultr_metrics_cancel': (_I, []),
     'ultr_host_device_pointer': (_I, [_P, ctypes.POINTER(ctypes.c_void_p)]),
     'ultr_sort_by_scores': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'ultr_clip_adagrad': (_I, [_P, _P, _P, _LL, _P, _F, _F, _F, _F, _I, _P, _P, _P]),

@@ -471,6 +471,12 @@ extern "C" int ultr_loss_flush(void* stream) {
   return launch_loss_now(p, as_stream(stream));
 }
 
+extern "C" int ultr_loss_cancel(void) {
+  const int was = g_pending_loss.kind != ULTR_RIDE_NONE ? 1 : 0;
+  g_pending_loss.kind = ULTR_RIDE_NONE;
+  return was;
+}
+
 extern "C" long long ultr_loss_workspace_floats(int B, int L) {
   const long long blocks = cdiv(B > 0 ? B : 1, 16);  // the short-list DLA kernel runs 16 lists per block
   long long ns = 4 + 4 * (long long)L;

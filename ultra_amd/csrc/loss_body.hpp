@@ -302,12 +302,12 @@ struct RemArgs {
 // One (list b, rank r) element: E-step posteriors, the Bernoulli ranker label and d loss / d score = sigmoid - label.
 // Elementwise, so the backward pass's first launch can evaluate it for its own rows (ultr_loss_rem_deferred).
 struct RemElem { float x, g, y, d, p_e1_r0_c0; };
-__device__ __forceinline__ RemElem rem_elem(const RemArgs& a, float bias, float p, unsigned int step, long long b, int r,
-                                            long long e) {
+// rem_elem_v takes the element's score and click by value (the fused training step has them on chip).
+__device__ __forceinline__ RemElem rem_elem_v(const RemArgs& a, float bias, float p, unsigned int step, long long b, int r,
+                                              long long e, float score, float c) {
 #pragma clang fp contract(off)
   RemElem v;
-  const float c = a.clicks[e];
-  v.x = a.scores[e] + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
+  v.x = score + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
   v.g = sigmoidf_(v.x);
   const float den = 1.f - p * v.g;
   v.p_e1_r0_c0 = p * (1.f - v.g) / den;              // :140-141
@@ -325,6 +325,10 @@ __device__ __forceinline__ RemElem rem_elem(const RemArgs& a, float bias, float 
   v.y = v.y > 0.f ? v.y : 0.f;  // ceil(-0.x) = -0 -> 0
   v.d = v.g - v.y;
   return v;
+}
+__device__ __forceinline__ RemElem rem_elem(const RemArgs& a, float bias, float p, unsigned int step, long long b, int r,
+                                            long long e) {
+  return rem_elem_v(a, bias, p, step, b, r, e, a.scores[e], a.clicks[e]);
 }
 
 __device__ __forceinline__ void rem_loss_small_body(const RemArgs& a, unsigned int bid, unsigned int nb, float* s_acc,

@@ -305,11 +305,17 @@ extern "C" int ultr_metrics_deferred(const float* scores, const float* labels, c
     rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, as_stream(stream));
     if (rc) return rc;
   }
-  if (a.P > 64 || nblocks > 64) return launch_metrics_now(a, nblocks, as_stream(stream));  // too big to ride along
+  if (a.P > 64) return launch_metrics_now(a, nblocks, as_stream(stream));  // only the short-list path has a body to carry
   g_pending_metrics.on = true;
   g_pending_metrics.a = a;
   g_pending_metrics.nblocks = nblocks;
   return ULTR_OK;
+}
+
+extern "C" int ultr_metrics_cancel(void) {
+  const int was = g_pending_metrics.on ? 1 : 0;
+  g_pending_metrics.on = false;
+  return was;
 }
 
 extern "C" int ultr_metrics_flush(void* stream) {

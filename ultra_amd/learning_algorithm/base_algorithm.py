@@ -324,14 +324,45 @@ class BaseAlgorithm(ABC):
         L = self.rank_list_size
         batch = self._to_device_batch(input_feed, L)
         tb = self._train_buffers(batch.B)
+        if self._fused_ok(batch):
+            self._step_local_fused(tb, batch)
+            self._pending = (tb, batch)
+            return
         scores = self.ranking_model(L, batch, tb['scores'])
         try:
             self._loss(tb, batch, scores)                      # d_scores + additive statistics (may be parked)
+            self._after_scores(tb, batch, scores)
             self._backward_and_metrics(tb, batch, scores)
         finally:
             # a parked loss that no backward pass carried (an error in between) is launched while its buffers are alive
             _lib.lib().ultr_loss_flush(_lib.current_stream())
         self._pending = (tb, batch)
+
+    def _after_scores(self, tb, batch, scores):
+        """Hook: rank-local summaries an algorithm forms from the scores with plain tensor ops (once they exist)."""
+
+    # ULTR_FUSED_STEP=0: forward, loss and backward pass as separate calls even for short lists
+    fused_step = os.environ.get('ULTR_FUSED_STEP', '1') != '0'
+
+    def _fused_ok(self, batch):
+        """Short lists run forward + loss gradient + backward as ONE call (ultr_dnn_train_fused)."""
+        return self.fused_step and self._loss_rides() and self.model.fused_supported(batch.B, batch.L)
+
+    def _step_local_fused(self, tb, batch):
+        scores = tb['scores']
+        lib = _lib.lib()
+        try:
+            self._loss(tb, batch, scores)                      # parked: the fused call differentiates it
+            self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS, deferred=True)
+            tb['sumsq_valid'] = self.fused_tail and self.world == 1
+            self.model.train_fused(batch.table, batch.table_stats, batch.n_rows, batch.docids[:self.rank_list_size],
+                                   scores, tb['grads'], tb['sumsq'] if tb['sumsq_valid'] else None)
+            _lib.check(lib.ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
+            self._after_scores(tb, batch, scores)
+        except Exception:
+            lib.ultr_metrics_cancel()                          # the scores these requests describe never came to be
+            lib.ultr_loss_cancel()
+            raise
 
     def _backward_and_metrics(self, tb, batch, scores):
         # The in-step metrics need only the scores and the list weights: they run on a side stream (a parallel

@@ -44,6 +44,8 @@ class NavieAlgorithm(BaseAlgorithm):
             _lib.ptr(scores), _lib.ptr(batch.labels), _lib.ptr(self._ones), batch.B, L, self.loss_kind,
             _lib.ptr(tb['d_scores']), _lib.ptr(tb['stats']), _lib.ptr(tb['list_weights']), _lib.ptr(tb['loss_ws']),
             _lib.current_stream()), 'ultr_loss_ipw_fwdbwd')
+
+    def _after_scores(self, tb, batch, scores):
         # Max/Min_output_score summaries (:93-119): rank-local values, with and without the pad rows (-100000)
         local = tb['local']
         no_pad = torch.where(batch.docids == batch.n_rows, torch.full_like(scores, float(self.PADDING_SCORE)), scores)

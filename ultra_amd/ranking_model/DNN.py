@@ -193,6 +193,30 @@ class DNN(BaseRankingModel):
             'ultr_dnn_backward')
         return grads
 
+    def fused_supported(self, B, L):
+        """True when (B lists of L) can run as the fused training step (``ultr_dnn_train_fused``)."""
+        return self._fused_workspace(B, L) is not None
+
+    def _fused_workspace(self, B, L):
+        key = ('fused', B, L)
+        if key not in self._ws:
+            nbytes = _lib.lib().ultr_dnn_fused_workspace_bytes(self.desc, int(B), int(L))
+            if nbytes < 0:
+                raise _lib.UltrError(_lib.lib().ultr_last_error().decode())
+            self._ws[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device) if nbytes > 0 else None
+        return self._ws[key]
+
+    def train_fused(self, table, table_stats, n_rows, docids_lb, scores, grads, sumsq=None):
+        """Forward, the parked loss request's gradient and the backward pass in one call: scores [L, B] and
+        grads[:n_params] are written (``ultr_dnn_train_fused``)."""
+        L, B = docids_lb.shape
+        ws = self._fused_workspace(B, L)
+        _lib.check(_lib.lib().ultr_dnn_train_fused(
+            self.desc, _lib.ptr(self.params), _lib.ptr(table), _lib.ptr(table_stats), int(n_rows), int(table.stride(0)),
+            _lib.ptr(docids_lb), int(B), int(L), _lib.ptr(ws), _lib.ptr(scores), _lib.ptr(grads), _lib.ptr(sumsq),
+            _lib.current_stream()), 'ultr_dnn_train_fused')
+        return scores
+
     def sumsq_count(self):
         return int(_lib.lib().ultr_dnn_sumsq_count(self.desc))
 
