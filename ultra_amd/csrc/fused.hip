@@ -25,12 +25,18 @@ constexpr int kTcMiscFloats = (ULTR_MAX_LAYERS + 1) * 32 + 32;  // row statistic
 
 #ifdef ULTR_STAMPS
 __device__ long long g_tc_stamps[1024 * 32];
+__device__ long long g_tc_wstamps[1024 * 8 * 4];
+#define TC_WSTAMP(i)                                                                                                  \
+  do {                                                                                                                \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_tc_wstamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (i)] = wall_clock64(); \
+  } while (0)
 #define TC_STAMP(i)                                                                                       \
   do {                                                                                                    \
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + (i)] = wall_clock64();       \
   } while (0)
 #else
 #define TC_STAMP(i) do { } while (0)
+#define TC_WSTAMP(i) do { } while (0)
 #endif
 
 struct TcArgs {
@@ -49,6 +55,7 @@ struct TcArgs {
   int panel_floats;                               // floats per panel
   int act_off[ULTR_MAX_LAYERS], act_ps[ULTR_MAX_LAYERS];  // LDS: activations of hidden layer j, [16][act_ps]
   int p1_off, p2_off, misc_off;
+  int dbg;
   DlaArgs dla; IpwArgs ipw; RemArgs rem; PdArgs pd;       // the one matching the kernel's RIDE is live
 };
 
@@ -58,10 +65,11 @@ struct TcFrag { float4 b[4]; };
 // of 64 output columns; fewer than 8 units split the contraction over the idle waves (KS slices, meeting in LDS).
 struct TcGeo {
   const float* W; int K, N, ld, U, Up, KS, ks, u_first, c_begin, c_last, nch;
+  int dbg;  // diagnostic builds (-DULTR_STAMPS): 1 no weight loads
 };
 __device__ __forceinline__ TcGeo tc_geo(const float* W, int K, int N, int ld, int w) {
   TcGeo g;
-  g.W = W; g.K = K; g.N = N; g.ld = ld;
+  g.W = W; g.K = K; g.N = N; g.ld = ld; g.dbg = 0;
   g.U = (N + 63) >> 6;
   int Up = 1;
   while (Up < g.U && Up < 8) Up <<= 1;
@@ -76,38 +84,90 @@ __device__ __forceinline__ TcGeo tc_geo(const float* W, int K, int N, int ld, in
   g.c_last = max(c_end - 1, 0);
   return g;
 }
-__device__ __forceinline__ void tc_wload(const TcGeo& g, int colc, int i, int kk, TcFrag& S) {
-  const int k0 = 16 * min(g.c_begin + i, g.c_last) + 4 * kk;
+// Chunk i of the wave's weight stream: rows 16 c + 4 kk + s (s = 0..3) of Wm, four consecutive columns from colc.
+// Full chunks: a wave-uniform row pointer (scalar registers) plus ONE per-lane 32-bit offset for all four loads.
+// FAST: the contraction length may stop short of the last chunk's 16 rows (layer 0 only: hidden widths are multiples
+// of 16); those rows are read all the same -- they lie inside the parameter buffer (checked on the host), are finite,
+// and meet zeros in the panel -- so the loop carries no clamps and no tail path.
+template <bool FAST>
+__device__ __forceinline__ void tc_wload(const TcGeo& g, int colc, unsigned voff, int i, int kk, TcFrag& S) {
+#ifdef ULTR_STAMPS
+  if (g.dbg & 1) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-    S.b[s] = *reinterpret_cast<const float4*>(g.W + (size_t)min(k0 + s, g.K - 1) * g.ld + colc);
+    for (int s = 0; s < 4; ++s) S.b[s] = make_float4(0.f, 1.f, 2.f, 3.f);
+    return;
+  }
+#endif
+  // Loads are UNCONDITIONAL: a branch around them would leave the number of loads in flight unknown at the loop
+  // header, and the compiler would then drain every outstanding load there (s_waitcnt vmcnt(0)) instead of waiting
+  // for the oldest chunk only.  Past the end of the stream (i >= nch) all lanes read the first 16 bytes of a row of
+  // the matrix's first chunk: one cache line per load, nothing new from L2.
+  const bool on = i < g.nch;  // wave-uniform
+  const int c = on ? g.c_begin + i : 0;
+  if (FAST || 16 * c + 16 <= g.K) {
+    const float* rowp = g.W + (size_t)(16 * c) * g.ld;
+    const unsigned vo = on ? voff : 0u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) S.b[s] = *reinterpret_cast<const float4*>(rowp + (size_t)(s * g.ld) + vo);
+  } else {  // the last, partial chunk: rows clamped into the matrix (the panel holds zeros there)
+    const int k0 = 16 * c + 4 * kk;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      S.b[s] = *reinterpret_cast<const float4*>(g.W + (size_t)min(k0 + s, g.K - 1) * g.ld + colc);
+  }
 }
-__device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcFrag& S0, TcFrag& S1) {
+template <bool FAST>
+__device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcFrag& S0, TcFrag& S1, TcFrag& S2) {
   if (g.u_first < g.U) {
     const int colc = min(64 * g.u_first + 4 * nn, g.ld - 4);
-    tc_wload(g, colc, 0, kk, S0);
-    tc_wload(g, colc, 1, kk, S1);
+    const unsigned voff = (unsigned)(4 * kk * g.ld + colc);
+    tc_wload<FAST>(g, colc, voff, 0, kk, S0);
+    tc_wload<FAST>(g, colc, voff, 1, kk, S1);
+    tc_wload<FAST>(g, colc, voff, 2, kk, S2);
   }
 }
 
-// The GEMM proper.  A: LDS panel [16][PS] (zero beyond K up to the next multiple of 16); once multiplied out it serves as
-// the split-K exchange buffer.  epi(u, acc) receives the finished unit: acc[t][r] = out[row 4 kk + r][col 64 u + 4 nn + t].
-// The first two weight chunks of the wave's first unit must already be in S0 / S1 (tc_prefetch).
-template <class Epi>
+// Four-stage rotation: three chunks of weights in flight while one is multiplied.
+#define TC_SB() __builtin_amdgcn_sched_barrier(0)
+#define TC_STREAM4(NCH, LOAD, COMPUTE)                          \
+  do {                                                          \
+    int i_ = 0;                                                 \
+    for (; i_ + 4 <= (NCH); i_ += 4) {                          \
+      LOAD(i_ + 3, S3); TC_SB(); COMPUTE(S0, i_); TC_SB();      \
+      LOAD(i_ + 4, S0); TC_SB(); COMPUTE(S1, i_ + 1); TC_SB();  \
+      LOAD(i_ + 5, S1); TC_SB(); COMPUTE(S2, i_ + 2); TC_SB();  \
+      LOAD(i_ + 6, S2); TC_SB(); COMPUTE(S3, i_ + 3); TC_SB();  \
+    }                                                           \
+    if (i_ < (NCH)) COMPUTE(S0, i_);                            \
+    if (i_ + 1 < (NCH)) COMPUTE(S1, i_ + 1);                    \
+    if (i_ + 2 < (NCH)) COMPUTE(S2, i_ + 2);                    \
+  } while (0)
+
+// The GEMM proper.  A: LDS panel [16][PS] (finite beyond K up to the next multiple of 16 in rows that matter: zero); once
+// multiplied out it serves as the split-K exchange buffer.  epi(u, acc) receives the finished unit:
+// acc[t][r] = out[row 4 kk + r][col 64 u + 4 nn + t].  The first three weight chunks of the wave's first unit must
+// already be in S0 / S1 / S2 (tc_prefetch).
+template <bool FAST, class Epi>
 __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn, int kk, int lane, TcFrag& S0,
-                                        TcFrag& S1, TcFrag& S2, Epi epi) {
+                                        TcFrag& S1, TcFrag& S2, TcFrag& S3, Epi epi, int stamp = -1) {
+  if (stamp >= 0) TC_STAMP(stamp);
+  const float* arow = A + nn * PS + 4 * kk + 16 * g.c_begin;
   for (int u = g.u_first; u < g.U; u += 8) {
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int colc = min(64 * u + 4 * nn, g.ld - 4);
+    const unsigned voff = (unsigned)(4 * kk * g.ld + colc);
     if (u != g.u_first) {
-      tc_wload(g, colc, 0, kk, S0);
-      tc_wload(g, colc, 1, kk, S1);
+      tc_wload<FAST>(g, colc, voff, 0, kk, S0);
+      tc_wload<FAST>(g, colc, voff, 1, kk, S1);
+      tc_wload<FAST>(g, colc, voff, 2, kk, S2);
     }
+    float4 a_cur = *reinterpret_cast<const float4*>(arow);
     auto compute = [&](TcFrag& S, int i) {
-      const float4 a4 = *reinterpret_cast<const float4*>(A + nn * PS + 16 * (g.c_begin + i) + 4 * kk);
-      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      // the panel values of the NEXT chunk are requested before this chunk's MFMAs: their LDS latency runs under them
+      const float4 a_nxt = *reinterpret_cast<const float4*>(arow + 16 * min(i + 1, g.nch - 1));
+      const float a[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].x, acc[0], 0, 0, 0);
@@ -115,14 +175,17 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].z, acc[2], 0, 0, 0);
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].w, acc[3], 0, 0, 0);
       }
+      a_cur = a_nxt;
     };
-#define TC_LOAD(i, S) tc_wload(g, colc, (i), kk, S)
+#define TC_LOAD(i, S) tc_wload<FAST>(g, colc, voff, (i), kk, S)
 #define TC_COMPUTE(S, i) compute(S, (i))
-    ULTR_STREAM_GEMM(g.nch, TC_LOAD, TC_COMPUTE);
+    TC_STREAM4(g.nch, TC_LOAD, TC_COMPUTE);
 #undef TC_LOAD
 #undef TC_COMPUTE
+    if (stamp >= 0) TC_STAMP(stamp + 1);
     if (g.KS > 1) {  // uniform over the workgroup (U < 8: exactly one unit per wave)
       lds_barrier();  // the panel has been multiplied out: the exchange buffer takes its place
+      if (stamp >= 0) TC_STAMP(stamp + 2);
       if (g.ks > 0) {
         float* dst = A + ((g.ks - 1) * g.Up + u) * 1024 + lane * 4;
 #pragma unroll
@@ -130,6 +193,7 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
           *reinterpret_cast<float4*>(dst + 256 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
       }
       lds_barrier();
+      if (stamp >= 0) TC_STAMP(stamp + 3);
       if (g.ks == 0) {
         for (int sl = 1; sl < g.KS; ++sl) {
           const float* srcp = A + ((sl - 1) * g.Up + u) * 1024 + lane * 4;
@@ -141,6 +205,7 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
         }
       }
     }
+    if (stamp >= 0) TC_STAMP(stamp + 4);
     if (g.ks == 0) epi(u, acc);
   }
   if (g.u_first >= g.U && g.KS > 1) {  // idle waves of a non-power-of-two unit count still meet the barriers
@@ -149,87 +214,89 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
   }
 }
 
-// Two rows (2w, 2w+1) of a width-K matrix, lane l holding columns 4 l + 256 q .. + 3.
-struct TcRows { float4 x[2][4]; };
-__device__ __forceinline__ void tc_rows_from_lds(const float* src, int stride, int K16, int nq, int w, int lane, TcRows& R) {
-#pragma unroll
-  for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < nq) R.x[r2][q] = *reinterpret_cast<const float4*>(src + (2 * w + r2) * stride + min(4 * lane + 256 * q, K16 - 4));
+// FAST kernels are compiled for the reference's default scorer (DNN.py:25-34: elu, layer normalisation) with every width a
+// multiple of 4: activation, LayerNorm switch and the per-element tail masks fold away.  The stages between the GEMMs
+// are bound by the NUMBER of instructions they issue (two waves per SIMD, ~2.6 cycles per instruction measured), so this
+// is worth 3-5x on them.  Everything else runs the generic instantiation.
+template <bool FAST> __device__ __forceinline__ float tc_actf(int kind, float z) {
+  if (FAST) return z > 0.f ? z : expm1_neg(z);
+  return act_fwd(kind, z);
 }
-// two-pass (mean, rstd) of the two rows, interleaved (biased variance, keras LayerNormalization)
-__device__ __forceinline__ void tc_row_stats(const TcRows& R, int K, int nq, int lane, float eps, float (&mean)[2], float (&rstd)[2]) {
-  float sm[2], m2[2];
-#pragma unroll
-  for (int r2 = 0; r2 < 2; ++r2) {
-    sm[r2] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < nq) {
-        const int k = 4 * lane + 256 * q;
-        sm[r2] += (k < K ? R.x[r2][q].x : 0.f) + (k + 1 < K ? R.x[r2][q].y : 0.f) + (k + 2 < K ? R.x[r2][q].z : 0.f) +
-                  (k + 3 < K ? R.x[r2][q].w : 0.f);
-      }
-  }
-#pragma unroll
-  for (int r2 = 0; r2 < 2; ++r2) mean[r2] = wave_sum(sm[r2]) / (float)K;
-#pragma unroll
-  for (int r2 = 0; r2 < 2; ++r2) {
-    m2[r2] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < nq) {
-        const int k = 4 * lane + 256 * q;
-        const float d0 = k < K ? R.x[r2][q].x - mean[r2] : 0.f, d1 = k + 1 < K ? R.x[r2][q].y - mean[r2] : 0.f;
-        const float d2 = k + 2 < K ? R.x[r2][q].z - mean[r2] : 0.f, d3 = k + 3 < K ? R.x[r2][q].w - mean[r2] : 0.f;
-        m2[r2] = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, fmaf(d0, d0, m2[r2]))));
-      }
-  }
-#pragma unroll
-  for (int r2 = 0; r2 < 2; ++r2) rstd[r2] = 1.f / sqrtf(wave_sum(m2[r2]) / (float)K + eps);
+template <bool FAST> __device__ __forceinline__ float tc_actg(int kind, float a) {
+  if (FAST) return a > 0.f ? 1.f : a + 1.f;
+  return act_grad_from_out(kind, a);
 }
+// 1 / sqrt(v): the hardware reciprocal square root (1 ulp) in the fast kernels
+template <bool FAST> __device__ __forceinline__ float tc_rsqrt(float v) {
+  if (FAST) return __builtin_amdgcn_rsqf(v);
+  return 1.f / sqrtf(v);
+}
+template <bool FAST> __device__ __forceinline__ bool tc_ok(int k, int e, int K) { return FAST ? k < K : k + e < K; }
+__device__ __forceinline__ void tc_unpack(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 
-template <int RIDE>
+// NQ: float4 per lane and row the stages are compiled for (256 NQ >= the widest layer input, rounded up to 16)
+template <int RIDE, bool FAST, int NQ>
 __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = lane & 15, kk = lane >> 4;
   const int L = p.L, B = p.B, nl = p.nl, H = p.H, PS = p.PS;
+  const bool has_ln = FAST ? true : p.has_ln != 0;
+  const int act = p.activation;
   const long long list0 = (long long)blockIdx.x * nl;
   float* P1 = smem + p.p1_off;
   float* P2 = smem + p.p2_off;
   float* s_stat = smem + p.misc_off;                       // [layer][16][2]
   float* s_score = s_stat + (ULTR_MAX_LAYERS + 1) * 32;    // [16]
-  TcFrag S0, S1, S2;
+  TcFrag S0, S1, S2, S3;
   TC_STAMP(0);
 
-  // ---- the wave's two rows: local row rr = li * L + l  <->  list list0 + li, rank l
+  // ---- the wave's two rows, w and w + 8 (valid rows spread evenly over the SIMDs): local row rr = li * L + l  <->
+  // list list0 + li, rank l.  Rows beyond the workgroup's lists are skipped by every stage; their LDS rows only have
+  // to hold finite numbers (the MFMA tiles carry them along, nothing reads their results).
   bool rvalid[2];
   long long re[2], rm[2];  // position-major element index (scores, clicks, doc ids), list-major row (xhat, dz)
 #pragma unroll
   for (int r2 = 0; r2 < 2; ++r2) {
-    const int rr = 2 * w + r2, li = rr / L, l = rr - li * L;
+    const int rr = w + 8 * r2, li = rr / L, l = rr - li * L;
     const long long b = list0 + li;
     rvalid[r2] = li < nl && b < B;
     re[r2] = rvalid[r2] ? (long long)l * B + b : 0;
     rm[r2] = rvalid[r2] ? b * L + l : 0;
   }
-  // ---- the lane's element of the loss: list list0 + lane / 16, rank lane % 16
+  // ---- layer 0: weights first, then the rows (doc id -> table row + statistics: two dependent round trips)
+  TcGeo g = tc_geo(p.W[0], p.K[0], p.N[0], p.ldn[0], w);
+  g.dbg = p.dbg;
+  tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
+  int docid[2];
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) docid[r2] = rvalid[r2] ? p.docids[re[r2]] : p.n_rows;
+  float4 gm[NQ], btq[NQ];  // gamma / beta of the coming input stage, this lane's columns
+  {
+    const int K = p.K[0], nq = (((K + 15) & ~15) + 255) >> 8, k_last4 = ((K + 3) & ~3) - 4;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      gm[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+      btq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < nq && has_ln) {
+        const int kc = min(4 * lane + 256 * q, k_last4);
+        gm[q] = *reinterpret_cast<const float4*>(p.gamma[0] + kc);
+        btq[q] = *reinterpret_cast<const float4*>(p.beta[0] + kc);
+      }
+    }
+  }
+  // ---- the lane's element of the loss: list list0 + lane / 16, rank lane % 16 (loads now, arithmetic later)
   const int li_l = lane >> 4, r_l = lane & 15;
   const long long b_l = list0 + li_l;
   const bool live = li_l < nl && r_l < L && b_l < B;
   const long long e_l = live ? (long long)r_l * B + b_l : 0;
   float c_l = 0.f, wgt_l = 0.f, pd_tp = 1.f, pd_tm = 1.f, rem_bias = 0.f, rem_p = 1.f;
   unsigned int rem_step = 0u;
-  if (RIDE == ULTR_RIDE_DLA) {
-    c_l = live ? p.dla.clicks[e_l] : 0.f;
-    wgt_l = dla_tower(p.dla.prop_params, L, r_l, p.dla.prob_kind, p.dla.max_pw).pw;
-  }
+  if (RIDE == ULTR_RIDE_DLA) c_l = live ? p.dla.clicks[e_l] : 0.f;
   if (RIDE == ULTR_RIDE_IPW) {
     c_l = live ? p.ipw.clicks[e_l] : 0.f;
-    wgt_l = live ? ipw_weight(p.ipw, e_l, r_l, c_l) : 0.f;
+    if (!p.ipw.ipw_table) wgt_l = live ? p.ipw.pw[e_l] : 0.f;
   }
   if (RIDE == ULTR_RIDE_PD) {
     c_l = live ? p.pd.clicks[e_l] : 0.f;
@@ -243,154 +310,244 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     rem_p = r_l < L ? p.rem.propensity[r_l] : 1.f;
   }
 
-  // ================================ forward: hidden layers ================================
-  for (int j = 0; j < H; ++j) {
-    const int K = p.K[j], K16 = (K + 15) & ~15, N = p.N[j], ldn = p.ldn[j];
-    const TcGeo g = tc_geo(p.W[j], K, N, ldn, w);
-    tc_prefetch(g, nn, kk, S0, S1);  // the weight stream starts before the rows are ready
+  // ---- L2 warm-up: every workgroup starts at once, so the FIRST touch of each weight line would otherwise be paid
+  // by all of them together, layer by layer, at HBM / Infinity-Cache latency in the middle of a GEMM.  The 32
+  // workgroups that (by the round-robin placement; speed only) share an XCD each touch a slice of the later layers'
+  // weights now, while the gather's round trips are in flight.
+  float warm = 0.f;
+  {
+    const int xi = blockIdx.x >> 3, nx = (gridDim.x + 7) >> 3;
+    for (int j = 0; j < H; ++j) {
+      const long long tot = (long long)p.K[j] * p.ldn[j], totT = j >= 1 ? (long long)p.N[j] * ((p.K[j] + 3) & ~3) : 0;
+      const long long lines = (tot + 31) >> 5, linesT = (totT + 31) >> 5;
+      const long long per = (lines + nx - 1) / nx, perT = (linesT + nx - 1) / nx;
+      for (long long i = xi * per + tid; i < min((xi + 1) * per, lines); i += kTcThreads) warm += p.W[j][i * 32];
+      for (long long i = xi * perT + tid; i < min((xi + 1) * perT, linesT); i += kTcThreads) warm += p.WT[j][i * 32];
+    }
+  }
 
-    // ---- input stage: rows 2w, 2w+1; lanes run along the row
-    {
-      const int nq = (K16 + 255) >> 8;  // <= 4 (widths <= 1024)
-      const int k_last4 = ((K + 3) & ~3) - 4, ldxh = (K + 3) & ~3;
-      float4 gm[4], btq[4];
+  // ---- input stage of layer 0: gathered rows, normalised with the table's statistics
+  {
+    const int K = p.K[0], K16 = (K + 15) & ~15, nq = (K16 + 255) >> 8, ldxh = (K + 3) & ~3;
+    float4 x[2][NQ];
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+    bool pad[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        gm[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-        btq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < nq && p.has_ln) {
-          const int kc = min(4 * lane + 256 * q, k_last4);
-          gm[q] = *reinterpret_cast<const float4*>(p.gamma[j] + kc);
-          btq[q] = *reinterpret_cast<const float4*>(p.beta[j] + kc);
-        }
-      }
-      TcRows R;
-      float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
-      bool pad[2] = {false, false};
-      if (j == 0) {
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-          const int d = rvalid[r2] ? p.docids[re[r2]] : p.n_rows;  // rows beyond the workgroup's lists: the zero row
-          pad[r2] = d >= p.n_rows;
-          const float* src = p.table + (long long)(pad[r2] ? 0 : d) * p.ldx;
-          if (p.has_ln) {
-            mean[r2] = p.row_stats[2 * (long long)d];
-            rstd[r2] = p.row_stats[2 * (long long)d + 1];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < nq) R.x[r2][q] = *reinterpret_cast<const float4*>(src + min(4 * lane + 256 * q, p.ldx - 4));
-        }
-      } else {
-        tc_rows_from_lds(smem + p.act_off[j - 1], p.act_ps[j - 1], K16, nq, w, lane, R);
-        if (p.has_ln) {
-          tc_row_stats(R, K, nq, lane, p.eps, mean, rstd);
-          if (lane == 0) {
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2)
-              *reinterpret_cast<float2*>(s_stat + (j * 16 + 2 * w + r2) * 2) = make_float2(mean[r2], rstd[r2]);
-          }
-        }
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int d = docid[r2];
+      pad[r2] = d >= p.n_rows;
+      const float* src = p.table + (long long)(pad[r2] ? 0 : d) * p.ldx;
+      if (has_ln) {
+        const float2 st = *reinterpret_cast<const float2*>(p.row_stats + 2 * (long long)d);
+        mean[r2] = st.x;
+        rstd[r2] = st.y;
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NQ; ++q)
+        if (q < nq) x[r2][q] = *reinterpret_cast<const float4*>(src + min(4 * lane + 256 * q, p.ldx - 4));
+    }
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int row = w + 8 * r2;
+      const float rs = pad[r2] ? 0.f : rstd[r2], mu = pad[r2] ? 0.f : mean[r2];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
         if (q < nq) {
           const int k = 4 * lane + 256 * q;
-          const float4 gq = gm[q], bt = btq[q];
+          float xs[4], gg[4], bb[4], xh[4], a[4];
+          tc_unpack(x[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb);
 #pragma unroll
-          for (int r2 = 0; r2 < 2; ++r2) {
-            const int row = 2 * w + r2;
-            const float rs = pad[r2] ? 0.f : rstd[r2], mu = pad[r2] ? 0.f : mean[r2];
-            float4 xh, a;  // (x - mean) * rstd * gamma + beta ; a zero feature row normalises to beta
-            xh.x = k < K ? (R.x[r2][q].x - mu) * rs : 0.f;
-            xh.y = k + 1 < K ? (R.x[r2][q].y - mu) * rs : 0.f;
-            xh.z = k + 2 < K ? (R.x[r2][q].z - mu) * rs : 0.f;
-            xh.w = k + 3 < K ? (R.x[r2][q].w - mu) * rs : 0.f;
-            a.x = k < K ? fmaf(xh.x, gq.x, bt.x) : 0.f;
-            a.y = k + 1 < K ? fmaf(xh.y, gq.y, bt.y) : 0.f;
-            a.z = k + 2 < K ? fmaf(xh.z, gq.z, bt.z) : 0.f;
-            a.w = k + 3 < K ? fmaf(xh.w, gq.w, bt.w) : 0.f;
-            if (k < K16) {
-              *reinterpret_cast<float4*>(P1 + row * PS + k) = a;
-              if (rvalid[r2] && k < ldxh) *reinterpret_cast<float4*>(p.xhat[j] + rm[r2] * ldxh + k) = xh;
-            }
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = tc_ok<FAST>(k, e, K);
+            xh[e] = ok ? (xs[e] - mu) * rs : 0.f;  // a zero feature row normalises to beta
+            a[e] = ok ? fmaf(xh[e], gg[e], bb[e]) : 0.f;
+          }
+          if (k < K16) {
+            *reinterpret_cast<float4*>(P1 + row * PS + k) = make_float4(a[0], a[1], a[2], a[3]);
+            if (rvalid[r2] && k < ldxh)
+              *reinterpret_cast<float4*>(p.xhat[0] + rm[r2] * ldxh + k) = make_float4(xh[0], xh[1], xh[2], xh[3]);
           }
         }
     }
-    TC_STAMP(1 + 3 * j);
-    lds_barrier();
+  }
+  TC_STAMP(1);
 
-    // ---- GEMM + epilogue: bias, activation -> the layer's activations (LDS, kept for the backward pass)
+  // ================================ forward: hidden layers ================================
+  float4 woq[NQ];   // the output layer's weights (loaded under the last hidden layer's GEMM)
+  for (int j = 0; j < H; ++j) {
+    const int N = p.N[j];
+    lds_barrier();  // the input panel is complete
+    if (j == 0) {   // the loss constants' arithmetic, off the gather's critical path
+      if (RIDE == ULTR_RIDE_DLA) wgt_l = dla_tower(p.dla.prop_params, L, r_l, p.dla.prob_kind, p.dla.max_pw).pw;
+      if (RIDE == ULTR_RIDE_IPW && p.ipw.ipw_table) wgt_l = live ? ipw_weight(p.ipw, e_l, r_l, c_l) : 0.f;
+    }
+    // gamma / beta of the NEXT input stage and this layer's bias ride along with the weight stream
+    {
+      const int K = p.K[j + 1], nq = (((K + 15) & ~15) + 255) >> 8, k_last4 = ((K + 3) & ~3) - 4;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        gm[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        btq[q] = woq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) {
+          const int kc = min(4 * lane + 256 * q, k_last4);
+          if (has_ln) {
+            gm[q] = *reinterpret_cast<const float4*>(p.gamma[j + 1] + kc);
+            btq[q] = *reinterpret_cast<const float4*>(p.beta[j + 1] + kc);
+          }
+          if (j + 1 == H) woq[q] = *reinterpret_cast<const float4*>(p.W[H] + kc);
+        }
+      }
+    }
     float* actj = smem + p.act_off[j];
     const int aps = p.act_ps[j];
-    tc_gemm(g, P1, PS, nn, kk, lane, S0, S1, S2, [&](int u, f32x4 (&acc)[4]) {
+    const float* biasj = p.bias[j];
+    tc_gemm<FAST>(g, P1, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
       const int col0 = 64 * u + 4 * nn;
       const int n16 = (N + 15) & ~15;
-      const float4 b4 = *reinterpret_cast<const float4*>(p.bias[j] + min(col0, ((N + 3) & ~3) - 4));
+      const float4 b4 = *reinterpret_cast<const float4*>(biasj + min(col0, ((N + 3) & ~3) - 4));
       if (col0 < n16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float4 z = make_float4(acc[0][r] + b4.x, acc[1][r] + b4.y, acc[2][r] + b4.z, acc[3][r] + b4.w);
-          float4 v = act4_rt(p.activation, z);
-          v.x = col0 < N ? v.x : 0.f;
-          v.y = col0 + 1 < N ? v.y : 0.f;
-          v.z = col0 + 2 < N ? v.z : 0.f;
-          v.w = col0 + 3 < N ? v.w : 0.f;
+          float4 v;
+          v.x = tc_ok<FAST>(col0, 0, N) ? tc_actf<FAST>(act, acc[0][r] + b4.x) : 0.f;
+          v.y = tc_ok<FAST>(col0, 1, N) ? tc_actf<FAST>(act, acc[1][r] + b4.y) : 0.f;
+          v.z = tc_ok<FAST>(col0, 2, N) ? tc_actf<FAST>(act, acc[2][r] + b4.z) : 0.f;
+          v.w = tc_ok<FAST>(col0, 3, N) ? tc_actf<FAST>(act, acc[3][r] + b4.w) : 0.f;
           *reinterpret_cast<float4*>(actj + (4 * kk + r) * aps + col0) = v;
         }
       }
-    });
+    }, j == 2 ? 10 : -1);
     TC_STAMP(2 + 3 * j);
-    lds_barrier();
+    if (j + 1 < H) {  // the next layer's weight stream starts before its rows are normalised
+      g = tc_geo(p.W[j + 1], p.K[j + 1], p.N[j + 1], p.ldn[j + 1], w);
+      g.dbg = p.dbg;
+      tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
+    }
+    lds_barrier();  // the layer's activations are complete
     TC_STAMP(3 + 3 * j);
+    if (j + 1 == H) break;
+
+    // ---- input stage of layer j + 1: LayerNorm of the activations -> panel (and xhat to memory for the weight gradients)
+    {
+      const int K = N, K16 = (K + 15) & ~15, nq = (K16 + 255) >> 8, ldxh = (K + 3) & ~3;
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        if (!rvalid[r2]) continue;  // wave-uniform
+        const int row = w + 8 * r2;
+        float4 x[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q < nq) x[q] = *reinterpret_cast<const float4*>(actj + row * aps + min(4 * lane + 256 * q, K16 - 4));
+        float mean = 0.f, rstd = 1.f;
+        if (has_ln) {  // two-pass statistics (biased variance, keras LayerNormalization)
+          float sm = 0.f;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              float xs[4];
+              tc_unpack(x[q], xs);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sm += tc_ok<FAST>(k, e, K) ? xs[e] : 0.f;
+            }
+          mean = wave_sum(sm) * (1.f / (float)K);
+          float m2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              float xs[4];
+              tc_unpack(x[q], xs);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float dd = tc_ok<FAST>(k, e, K) ? xs[e] - mean : 0.f;
+                m2 = fmaf(dd, dd, m2);
+              }
+            }
+          rstd = tc_rsqrt<FAST>(wave_sum(m2) * (1.f / (float)K) + p.eps);
+          if (lane == 0) *reinterpret_cast<float2*>(s_stat + ((j + 1) * 16 + row) * 2) = make_float2(mean, rstd);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q < nq) {
+            const int k = 4 * lane + 256 * q;
+            float xs[4], gg[4], bb[4], xh[4], a[4];
+            tc_unpack(x[q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool ok = tc_ok<FAST>(k, e, K);
+              xh[e] = ok ? (xs[e] - mean) * rstd : 0.f;
+              a[e] = ok ? fmaf(xh[e], gg[e], bb[e]) : 0.f;
+            }
+            if (k < K16) {
+              *reinterpret_cast<float4*>(P1 + row * PS + k) = make_float4(a[0], a[1], a[2], a[3]);
+              if (k < ldxh) *reinterpret_cast<float4*>(p.xhat[j + 1] + rm[r2] * ldxh + k) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+            }
+          }
+      }
+    }
+    TC_STAMP(4 + 3 * j);
   }
 
   // ================================ output layer, loss, output-layer backward ================================
   const int Ko = p.K[H], Ko16 = (Ko + 15) & ~15, nqo = (Ko16 + 255) >> 8;
-  TcRows R;
-  float4 gm[4], btq[4], woq[4];
+  float4 xo[2][NQ];
   float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
   {
-    const int k_last4 = ((Ko + 3) & ~3) - 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      gm[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-      btq[q] = woq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < nqo) {
-        const int kc = min(4 * lane + 256 * q, k_last4);
-        if (p.has_ln) {
-          gm[q] = *reinterpret_cast<const float4*>(p.gamma[H] + kc);
-          btq[q] = *reinterpret_cast<const float4*>(p.beta[H] + kc);
-        }
-        woq[q] = *reinterpret_cast<const float4*>(p.W[H] + kc);
-      }
-    }
-    tc_rows_from_lds(smem + p.act_off[H - 1], p.act_ps[H - 1], Ko16, nqo, w, lane, R);
-    if (p.has_ln) tc_row_stats(R, Ko, nqo, lane, p.eps, mean, rstd);
-    float dot[2] = {0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < nqo) {
-        const int k = 4 * lane + 256 * q;
-        const float xs[2][4] = {{R.x[0][q].x, R.x[0][q].y, R.x[0][q].z, R.x[0][q].w},
-                                {R.x[1][q].x, R.x[1][q].y, R.x[1][q].z, R.x[1][q].w}};
-        const float gg[4] = {gm[q].x, gm[q].y, gm[q].z, gm[q].w}, bb[4] = {btq[q].x, btq[q].y, btq[q].z, btq[q].w};
-        const float ww[4] = {woq[q].x, woq[q].y, woq[q].z, woq[q].w};
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = k + e < Ko ? fmaf((xs[r2][e] - mean[r2]) * rstd[r2], gg[e], bb[e]) : 0.f;
-            dot[r2] = fmaf(a, ww[e], dot[r2]);
-          }
-      }
+    const float* actl = smem + p.act_off[H - 1];
+    const int aps = p.act_ps[H - 1];
     const float ob = p.bias[H][0];
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
-      const float sc = wave_sum(dot[r2]) + ob;
+      if (!rvalid[r2]) continue;
+      const int row = w + 8 * r2;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (q < nqo) xo[r2][q] = *reinterpret_cast<const float4*>(actl + row * aps + min(4 * lane + 256 * q, Ko16 - 4));
+      if (has_ln) {
+        float sm = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q < nqo) {
+            const int k = 4 * lane + 256 * q;
+            float xs[4];
+            tc_unpack(xo[r2][q], xs);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sm += tc_ok<FAST>(k, e, Ko) ? xs[e] : 0.f;
+          }
+        mean[r2] = wave_sum(sm) * (1.f / (float)Ko);
+        float m2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q < nqo) {
+            const int k = 4 * lane + 256 * q;
+            float xs[4];
+            tc_unpack(xo[r2][q], xs);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dd = tc_ok<FAST>(k, e, Ko) ? xs[e] - mean[r2] : 0.f;
+              m2 = fmaf(dd, dd, m2);
+            }
+          }
+        rstd[r2] = tc_rsqrt<FAST>(wave_sum(m2) * (1.f / (float)Ko) + p.eps);
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (q < nqo) {
+          const int k = 4 * lane + 256 * q;
+          float xs[4], gg[4], bb[4], ww[4];
+          tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb); tc_unpack(woq[q], ww);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = tc_ok<FAST>(k, e, Ko) ? fmaf((xs[e] - mean[r2]) * rstd[r2], gg[e], bb[e]) : 0.f;
+            dot = fmaf(a, ww[e], dot);
+          }
+        }
+      const float sc = wave_sum(dot) + ob;
       if (lane == 0) {
-        s_score[2 * w + r2] = sc;
-        if (rvalid[r2]) p.scores[re[r2]] = sc;
+        s_score[row] = sc;
+        p.scores[re[r2]] = sc;
       }
     }
   }
@@ -423,7 +580,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     if (w == 0 && live && r_l == 0 && p.list_weights && RIDE != ULTR_RIDE_PD) p.list_weights[b_l] = lw / (float)L;
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
-      const int rr = 2 * w + r2, li = rr / L, l = rr - li * L;
+      const int rr = w + 8 * r2, li = rr / L, l = rr - li * L;
       const int src = li < 4 ? 16 * li + l : 0;
       const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ds), src));
       go[r2] = rvalid[r2] ? v : 0.f;
@@ -433,84 +590,84 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   // ---- output-layer backward: dz of the last hidden layer (-> P1 and memory) and the parameter-gradient partials
   {
     const int ldz = p.ldn[H - 1];
-    float* s_out = P2;  // [8 waves][3 Ko + 1]
-    float db = go[0] + go[1];
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    if (p.has_ln) {
+    float* mine = P2 + w * (3 * Ko + 1);  // [8 waves][3 Ko + 1]
+    float aW[NQ][4], aG[NQ][4], aB[NQ][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (q < nqo) {
-          const int k = 4 * lane + 256 * q;
-          const float gg[4] = {gm[q].x, gm[q].y, gm[q].z, gm[q].w}, ww[4] = {woq[q].x, woq[q].y, woq[q].z, woq[q].w};
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-          for (int r2 = 0; r2 < 2; ++r2) {
-            const float xs[4] = {R.x[r2][q].x, R.x[r2][q].y, R.x[r2][q].z, R.x[r2][q].w};
+      for (int e = 0; e < 4; ++e) aW[q][e] = aG[q][e] = aB[q][e] = 0.f;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      if (!rvalid[r2]) continue;
+      const int row = w + 8 * r2;
+      float s1 = 0.f, s2 = 0.f;
+      if (has_ln) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q < nqo) {
+            const int k = 4 * lane + 256 * q;
+            float xs[4], gg[4], ww[4];
+            tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(woq[q], ww);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float gw = k + e < Ko ? go[r2] * ww[e] : 0.f;
-              const float xh = (xs[e] - mean[r2]) * rstd[r2];
-              s1[r2] += gw * gg[e];
-              s2[r2] += gw * gg[e] * xh;
+              const float gwg = tc_ok<FAST>(k, e, Ko) ? go[r2] * ww[e] * gg[e] : 0.f;
+              s1 += gwg;
+              s2 = fmaf(gwg, (xs[e] - mean[r2]) * rstd[r2], s2);
             }
           }
-        }
-#pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        s1[r2] = wave_sum(s1[r2]) / (float)Ko;
-        s2[r2] = wave_sum(s2[r2]) / (float)Ko;
+        s1 = wave_sum(s1) * (1.f / (float)Ko);
+        s2 = wave_sum(s2) * (1.f / (float)Ko);
       }
-    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < nqo) {
-        const int k = 4 * lane + 256 * q;
-        const float gg[4] = {gm[q].x, gm[q].y, gm[q].z, gm[q].w}, bb[4] = {btq[q].x, btq[q].y, btq[q].z, btq[q].w};
-        const float ww[4] = {woq[q].x, woq[q].y, woq[q].z, woq[q].w};
-        float aW[4] = {0.f, 0.f, 0.f, 0.f}, aG[4] = {0.f, 0.f, 0.f, 0.f}, aB[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-          const float xs[4] = {R.x[r2][q].x, R.x[r2][q].y, R.x[r2][q].z, R.x[r2][q].w};
-          float o4[4];
+      for (int q = 0; q < NQ; ++q)
+        if (q < nqo) {
+          const int k = 4 * lane + 256 * q;
+          float xs[4], gg[4], bb[4], ww[4], o4[4];
+          tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb); tc_unpack(woq[q], ww);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool ok = k + e < Ko;
+            const bool ok = tc_ok<FAST>(k, e, Ko);
             const float gw = ok ? go[r2] * ww[e] : 0.f;
             float dx = gw;
-            if (p.has_ln) {
+            if (has_ln) {
               const float xh = (xs[e] - mean[r2]) * rstd[r2];
-              aW[e] += ok ? (gg[e] * xh + bb[e]) * go[r2] : 0.f;
-              aG[e] += gw * xh;
-              aB[e] += gw;
-              dx = rstd[r2] * (gw * gg[e] - s1[r2] - xh * s2[r2]);
+              aW[q][e] += ok ? fmaf(gg[e], xh, bb[e]) * go[r2] : 0.f;
+              aG[q][e] = fmaf(gw, xh, aG[q][e]);
+              aB[q][e] += gw;
+              dx = rstd[r2] * (gw * gg[e] - s1 - xh * s2);
             } else {
-              aW[e] += ok ? xs[e] * go[r2] : 0.f;
+              aW[q][e] += ok ? xs[e] * go[r2] : 0.f;
             }
-            o4[e] = ok ? dx * act_grad_from_out(p.activation, xs[e]) : 0.f;
+            o4[e] = ok ? dx * tc_actg<FAST>(act, xs[e]) : 0.f;
           }
-          const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
           if (k < Ko16) {
-            *reinterpret_cast<float4*>(P1 + (2 * w + r2) * PS + k) = ov;
-            if (rvalid[r2] && k < ldz) *reinterpret_cast<float4*>(p.dz[H - 1] + rm[r2] * ldz + k) = ov;
+            const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            *reinterpret_cast<float4*>(P1 + row * PS + k) = ov;
+            if (k < ldz) *reinterpret_cast<float4*>(p.dz[H - 1] + rm[r2] * ldz + k) = ov;
           }
         }
-        float* mine = s_out + w * (3 * Ko + 1);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (q < nqo) {
+        const int k = 4 * lane + 256 * q;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (k + e < Ko) {
-            mine[k + e] = aW[e];
-            mine[Ko + k + e] = aG[e];
-            mine[2 * Ko + k + e] = aB[e];
+            mine[k + e] = aW[q][e];
+            mine[Ko + k + e] = aG[q][e];
+            mine[2 * Ko + k + e] = aB[q][e];
           }
       }
-    if (lane == 0) s_out[w * (3 * Ko + 1) + 3 * Ko] = db;
+    if (lane == 0) mine[3 * Ko] = go[0] + go[1];
   }
 
   // the transposed weights of the first dgrad GEMM stream in under the partial-row reduction
   int cur_is_p1 = 1;
-  TcGeo gd = tc_geo(nullptr, 16, 16, 16, w);
   if (H >= 2) {
-    gd = tc_geo(p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w);
-    tc_prefetch(gd, nn, kk, S0, S1);
+    g = tc_geo(p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w);
+    g.dbg = p.dbg;
+    tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
   }
   TC_STAMP(17);
   lds_barrier();
@@ -535,13 +692,16 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     const int K = p.K[j], K16 = (K + 15) & ~15, nq = (K16 + 255) >> 8;
     const int ldo = p.ldn[j - 1];
     // what the row pass will need from memory, requested now
-    float4 gq4[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      gq4[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (q < nq && p.has_ln) gq4[q] = *reinterpret_cast<const float4*>(p.gamma[j] + min(4 * lane + 256 * q, ((K + 3) & ~3) - 4));
+    for (int q = 0; q < NQ; ++q) {
+      gm[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (q < nq && has_ln) gm[q] = *reinterpret_cast<const float4*>(p.gamma[j] + min(4 * lane + 256 * q, ((K + 3) & ~3) - 4));
     }
-    tc_gemm(gd, cur, PS, nn, kk, lane, S0, S1, S2, [&](int u, f32x4 (&acc)[4]) {
+#ifdef ULTR_STAMPS
+    if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memtime();
+#endif
+    if (j == 1) TC_WSTAMP(0);
+    tc_gemm<FAST>(g, cur, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
       const int col0 = 64 * u + 4 * nn;
       if (col0 < K16) {
 #pragma unroll
@@ -550,75 +710,79 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
       }
     });
     if (j >= 2) {  // the next layer's weight stream starts under the row pass
-      gd = tc_geo(p.WT[j - 1], p.N[j - 1], p.K[j - 1], (p.K[j - 1] + 3) & ~3, w);
-      tc_prefetch(gd, nn, kk, S0, S1);
+      g = tc_geo(p.WT[j - 1], p.N[j - 1], p.K[j - 1], (p.K[j - 1] + 3) & ~3, w);
+      g.dbg = p.dbg;
+      tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
     }
+#ifdef ULTR_STAMPS
+    if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memtime();
+#endif
+    if (j == 1) TC_WSTAMP(1);
     TC_STAMP(19 + 2 * (H - 1 - j));
     lds_barrier();
     {
-      TcRows D, A;
-      tc_rows_from_lds(nxt, PS, K16, nq, w, lane, D);
-      tc_rows_from_lds(smem + p.act_off[j - 1], p.act_ps[j - 1], K16, nq, w, lane, A);
-      float mu[2] = {0.f, 0.f}, rs[2] = {1.f, 1.f}, c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
-      if (p.has_ln) {
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-          const float2 st = *reinterpret_cast<const float2*>(s_stat + (j * 16 + 2 * w + r2) * 2);
-          mu[r2] = st.x;
-          rs[r2] = st.y;
-        }
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < nq) {
-              const int k = 4 * lane + 256 * q;
-              const float dd[4] = {D.x[r2][q].x, D.x[r2][q].y, D.x[r2][q].z, D.x[r2][q].w};
-              const float gg[4] = {gq4[q].x, gq4[q].y, gq4[q].z, gq4[q].w};
-              const float hh[4] = {A.x[r2][q].x, A.x[r2][q].y, A.x[r2][q].z, A.x[r2][q].w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float gv = k + e < K ? dd[e] * gg[e] : 0.f;
-                c1[r2] += gv;
-                c2[r2] += gv * (hh[e] - mu[r2]) * rs[r2];
-              }
-            }
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-          c1[r2] = wave_sum(c1[r2]) / (float)K;
-          c2[r2] = wave_sum(c2[r2]) / (float)K;
-        }
-      }
+      const float* acts = smem + p.act_off[j - 1];
+      const int aps = p.act_ps[j - 1];
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2) {
-        const int row = 2 * w + r2;
+        if (!rvalid[r2]) continue;
+        const int row = w + 8 * r2;
+        float4 d4[NQ], h4[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
+          if (q < nq) {
+            const int kc = min(4 * lane + 256 * q, K16 - 4);
+            d4[q] = *reinterpret_cast<const float4*>(nxt + row * PS + kc);
+            h4[q] = *reinterpret_cast<const float4*>(acts + row * aps + kc);
+          }
+        float mu = 0.f, rs = 1.f, c1 = 0.f, c2 = 0.f;
+        if (has_ln) {
+          const float2 st = *reinterpret_cast<const float2*>(s_stat + (j * 16 + row) * 2);
+          mu = st.x;
+          rs = st.y;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              float dd[4], gg[4], hh[4];
+              tc_unpack(d4[q], dd); tc_unpack(gm[q], gg); tc_unpack(h4[q], hh);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float gv = tc_ok<FAST>(k, e, K) ? dd[e] * gg[e] : 0.f;
+                c1 += gv;
+                c2 = fmaf(gv, (hh[e] - mu) * rs, c2);
+              }
+            }
+          c1 = wave_sum(c1) * (1.f / (float)K);
+          c2 = wave_sum(c2) * (1.f / (float)K);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
           if (q < nq) {
             const int k = 4 * lane + 256 * q;
-            const float dd[4] = {D.x[r2][q].x, D.x[r2][q].y, D.x[r2][q].z, D.x[r2][q].w};
-            const float gg[4] = {gq4[q].x, gq4[q].y, gq4[q].z, gq4[q].w};
-            const float hh[4] = {A.x[r2][q].x, A.x[r2][q].y, A.x[r2][q].z, A.x[r2][q].w};
-            float o4[4];
+            float dd[4], gg[4], hh[4], o4[4];
+            tc_unpack(d4[q], dd); tc_unpack(gm[q], gg); tc_unpack(h4[q], hh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float dx = dd[e];
-              if (p.has_ln) dx = rs[r2] * (dx * gg[e] - c1[r2] - (hh[e] - mu[r2]) * rs[r2] * c2[r2]);
-              o4[e] = k + e < K ? dx * act_grad_from_out(p.activation, hh[e]) : 0.f;
+              if (has_ln) dx = rs * (dx * gg[e] - c1 - (hh[e] - mu) * rs * c2);
+              o4[e] = tc_ok<FAST>(k, e, K) ? dx * tc_actg<FAST>(act, hh[e]) : 0.f;
             }
-            const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
             if (k < K16) {
+              const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
               if (j >= 2) *reinterpret_cast<float4*>(nxt + row * PS + k) = ov;
-              if (rvalid[r2] && k < ldo) *reinterpret_cast<float4*>(p.dz[j - 1] + rm[r2] * ldo + k) = ov;
+              if (k < ldo) *reinterpret_cast<float4*>(p.dz[j - 1] + rm[r2] * ldo + k) = ov;
             }
           }
       }
     }
+    if (j == 1) TC_WSTAMP(2);
     TC_STAMP(20 + 2 * (H - 1 - j));
     if (j >= 2) lds_barrier();
     cur_is_p1 ^= 1;
   }
   TC_STAMP(31);
+  if (warm == 1.2345e-30f && p.B < 0) p.outpart[0] = warm;  // never true: keeps the warm-up loads alive
 }
 
 // WT_j[n][k] = W_j[k][n] for the hidden layers j >= 1 (32 x 32 tiles through LDS), one launch for all of them
@@ -767,6 +931,12 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
 using namespace ultr;
 
 #ifdef ULTR_STAMPS
+extern "C" int ultr_debug_tc_wstamps(long long* host, int n) {
+  if (n > 1024 * 32) n = 1024 * 32;
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tc_wstamps), sizeof(long long) * (size_t)n);
+  return n;
+}
 extern "C" int ultr_debug_tc_stamps(long long* host, int n) {
   if (n > 1024 * 32) n = 1024 * 32;
   hipDeviceSynchronize();
@@ -781,11 +951,11 @@ extern "C" long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int
   return P.ok ? P.total * (long long)sizeof(float) : 0;
 }
 
-template <int RIDE>
-static int launch_chain(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
+template <int RIDE, bool FAST, int NQ>
+static int launch_chain2(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(train_chain_kernel<RIDE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(train_chain_kernel<RIDE, FAST, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       set_error("ultr_dnn_train_fused: cannot raise the dynamic LDS limit");
       return ULTR_EHIP;
@@ -796,9 +966,22 @@ static int launch_chain(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
   for (int j = 0; j < a.H; ++j) pw += (long long)a.K[j] * a.N[j] + (j >= 1 ? (long long)a.K[j] * a.N[j] : 0);
   {
     ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("train_chain_kernel/P%lld", pw) : "train_chain_kernel", st);
-    hipLaunchKernelGGL(train_chain_kernel<RIDE>, dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
+    hipLaunchKernelGGL((train_chain_kernel<RIDE, FAST, NQ>), dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
   }
   return check_launch("train_chain_kernel");
+}
+// `fast`: the reference's default scorer (elu, layer normalisation), input width a multiple of 4, hidden widths multiples
+// of 16, and layer 0's last weight chunk readable up to the next multiple of 16 rows (decided by the caller)
+template <int RIDE>
+static int launch_chain(const TcArgs& a, int nwg, size_t smem, bool fast, hipStream_t st) {
+  static const bool generic_only = [] { const char* e = getenv("ULTR_FUSED_GENERIC"); return e && e[0] == '1'; }();
+  if (fast && !generic_only) {
+    int maxk = 0;
+    for (int j = 0; j <= a.H; ++j) maxk = a.K[j] > maxk ? a.K[j] : maxk;
+    if (maxk <= 512) return launch_chain2<RIDE, true, 2>(a, nwg, smem, st);
+    return launch_chain2<RIDE, true, 4>(a, nwg, smem, st);
+  }
+  return launch_chain2<RIDE, false, 4>(a, nwg, smem, st);
 }
 
 extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params, const float* table,
@@ -864,13 +1047,19 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   a.scores = scores;
   a.outpart = ws + P.outpart;
   a.PS = P.PS; a.panel_floats = P.panel_floats; a.p1_off = P.p1_off; a.p2_off = P.p2_off; a.misc_off = P.misc_off;
+#ifdef ULTR_STAMPS
+  { const char* e = getenv("ULTR_TC_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
   a.dla = pl.dla; a.ipw = pl.ipw; a.rem = pl.rem; a.pd = pl.pd;
   a.list_weights = pl.kind == ULTR_RIDE_DLA ? pl.dla.list_weights : pl.kind == ULTR_RIDE_IPW ? pl.ipw.list_weights
                    : pl.kind == ULTR_RIDE_REM ? pl.rem.list_weights : nullptr;
-  if (pl.kind == ULTR_RIDE_DLA) rc = launch_chain<ULTR_RIDE_DLA>(a, P.nwg, P.smem_bytes, st);
-  else if (pl.kind == ULTR_RIDE_IPW) rc = launch_chain<ULTR_RIDE_IPW>(a, P.nwg, P.smem_bytes, st);
-  else if (pl.kind == ULTR_RIDE_REM) rc = launch_chain<ULTR_RIDE_REM>(a, P.nwg, P.smem_bytes, st);
-  else rc = launch_chain<ULTR_RIDE_PD>(a, P.nwg, P.smem_bytes, st);
+  bool fast = desc->activation == ULTR_ACT_ELU && has_ln && (P.K[0] & 3) == 0;
+  for (int j = 1; j <= H; ++j) fast = fast && (P.K[j] & 15) == 0;
+  fast = fast && desc->off_W[0] + (long long)((P.K[0] + 15) & ~15) * P.ldn[0] <= desc->n_params;
+  if (pl.kind == ULTR_RIDE_DLA) rc = launch_chain<ULTR_RIDE_DLA>(a, P.nwg, P.smem_bytes, fast, st);
+  else if (pl.kind == ULTR_RIDE_IPW) rc = launch_chain<ULTR_RIDE_IPW>(a, P.nwg, P.smem_bytes, fast, st);
+  else if (pl.kind == ULTR_RIDE_REM) rc = launch_chain<ULTR_RIDE_REM>(a, P.nwg, P.smem_bytes, fast, st);
+  else rc = launch_chain<ULTR_RIDE_PD>(a, P.nwg, P.smem_bytes, fast, st);
   if (rc) return rc;
 
   // ---- every weight-gradient GEMM + loss statistics + in-step metrics
