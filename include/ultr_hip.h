@@ -229,9 +229,13 @@ int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const 
  * L > 16, widths whose 16-row panels do not fit the 160 KB of LDS) -- use the separate entry points then; -1 on a bad
  * descriptor. */
 long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int B, int L);
+/* workspace: zero-initialised by the caller before its first use and used for this (desc, B, L) only.
+ * wt_fresh != 0: the transposed weight copies the workspace keeps for the dgrad GEMMs are current, i.e. the
+ *   parameters have not changed since the last ultr_clip_adagrad_fused call on this workspace; 0: they are rebuilt
+ *   first (one more small launch). */
 int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params, const float* table,
                          const float* table_stats, int n_rows, int ldx, const int* docids, int B, int L,
-                         void* workspace, float* scores, float* grads, float* sumsq, void* stream);
+                         void* workspace, int wt_fresh, float* scores, float* grads, float* sumsq, void* stream);
 
 /* ---- losses, forward + backward in one pass -------------------------------------------
  * All take scores/clicks position-major [L][B] and write d_scores [L][B] UN-NORMALISED: the
@@ -395,6 +399,17 @@ int ultr_clip_adagrad3(float* theta, float* acc, const float* grads, long long n
                        const float* denom_s, float scale_const_s, float l2_s, float clip_norm_s, float lr_s,
                        float* out_norm_s, const float* sumsq, int n_sumsq, long long n_covered,
                        const float* publish_src, float* publish_dst, int publish_n, void* stream);
+
+/* ultr_clip_adagrad3 for a scorer that trains through ultr_dnn_train_fused: the update launch also writes the updated
+ * hidden-layer weight matrices, transposed, into the fused step's workspace (same desc, B, L), so the next
+ * ultr_dnn_train_fused call may pass wt_fresh = 1.  theta must start with the scorer's flat parameter buffer. */
+int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, void* workspace, float* theta, float* acc,
+                            const float* grads, long long n, const float* denom, float scale_const, float l2,
+                            float clip_norm, float lr, int strategy, float* out_norm, float* ws, float* theta_s,
+                            float* acc_s, const float* grads_s, int n_s, const float* denom_s, float scale_const_s,
+                            float l2_s, float clip_norm_s, float lr_s, float* out_norm_s, const float* sumsq, int n_sumsq,
+                            long long n_covered, const float* publish_src, float* publish_dst, int publish_n,
+                            void* stream);
 
 /* Device-side address of a pinned (page-locked, mapped) host allocation; ULTR_EINVAL if the memory is not mapped. */
 int ultr_host_device_pointer(void* host, void** device);

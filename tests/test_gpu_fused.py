@@ -95,3 +95,28 @@ def test_fused_not_supported_shapes_fall_back():
     feed_dict, _ = feed.get_batch(data, check_validation=True)
     loss, _, _ = m.step(None, feed_dict, False)
     assert np.isfinite(float(loss))
+
+
+def test_transposed_weights_follow_external_parameter_writes():
+    """The fused step's dgrad GEMMs stream transposed weight copies that the update launch keeps current; a write to the
+    parameters from outside (checkpoint restore, a test poking values) must make the next step rebuild them."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    data = SyntheticData(200, 10, 24, seed=4, pad_frac=0.1)
+    exp = settings('DLA', '', 'hidden_layer_sizes=[64, 48, 32]')
+    m1, feed = make('DLA', data, exp, 64)
+    m2, _ = make('DLA', data, exp, 64)
+    m2.fused_step = False
+    rng = np.random.RandomState(3)
+    for step in range(4):
+        feed_dict, _ = feed.get_batch(data, check_validation=True)
+        u = torch.tensor(rng.uniform(size=(64, 10)).astype(np.float32)).cuda()
+        m1.metric_uniforms = m2.metric_uniforms = u
+        if step == 2:  # both models jump to new parameters
+            new = torch.randn_like(m1.model.params) * 0.05
+            new[m1.n_params:] = 0
+            mask = m1.model.params != 0
+            m1.model.params.copy_(torch.where(mask, new, m1.model.params))
+            m2.model.params.copy_(m1.model.params)
+        m1.step(None, feed_dict, False)
+        m2.step(None, feed_dict, False)
+        assert relerr_floor(m1.model.params.cpu().numpy(), m2.model.params.cpu().numpy(), 1e-4) < 2e-5, step

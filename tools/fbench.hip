@@ -12,6 +12,7 @@
 
 extern "C" int ultr_debug_tc_stamps(long long* host, int n) __attribute__((weak));
 extern "C" int ultr_debug_tc_wstamps(long long* host, int n) __attribute__((weak));
+extern "C" int ultr_debug_wg_stamps(long long* host, int n) __attribute__((weak));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 #define UK(x) do { int r_ = (x); if (r_ != 0) { printf("ultr error %d (%s) at %d\n", r_, ultr_last_error(), __LINE__); exit(1); } } while (0)
@@ -67,9 +68,10 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(clicks, hc.data(), M * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(prop, hprop.data(), (L + 1) * 4, hipMemcpyHostToDevice));
   UK(ultr_ln_row_stats(table, n_rows, F, F, 1e-3f, stats, nullptr));
+  int wt_fresh = 0;  // the parameters never change here: the copies stay current after the first call
   auto step = [&]() {
     UK(ultr_loss_dla_deferred(scores, clicks, B, L, prop, ULTR_LOSS_SOFTMAX, ULTR_PROB_SOFTMAX, -1.f, dsc, pgrads, lw, lstats, lws, nullptr));
-    UK(ultr_dnn_train_fused(&d, params, table, stats, n_rows, F, docids, B, L, ws, scores, grads, sumsq, nullptr));
+    UK(ultr_dnn_train_fused(&d, params, table, stats, n_rows, F, docids, B, L, ws, wt_fresh, scores, grads, sumsq, nullptr)); wt_fresh = 1;
   };
   for (int it = 0; it < 20; ++it) step();
   CK(hipDeviceSynchronize());
@@ -115,6 +117,18 @@ int main(int argc, char** argv) {
       for (int b = 0; b < NB; ++b) { const long long* s = &st[(size_t)b * NS]; if (s[0] && s[i]) { double v = (s[i] - t0) / 100.0; sum += v; mx = std::max(mx, v); mn = std::min(mn, v); c++; } }
       if (c) { printf("   stamp %2d: min %6.2f mean %6.2f max %6.2f us  (+%.2f)\n", i, mn, sum / c, mx, sum / c - prev); prev = sum / c; }
     }
+  }
+  if (ultr_debug_wg_stamps) {
+    std::vector<long long> st((size_t)1024 * 8);
+    ultr_debug_wg_stamps(st.data(), (int)st.size());
+    long long t0 = -1;
+    for (int b = 0; b < 1024; ++b) if (st[(size_t)b * 8] && (t0 < 0 || st[(size_t)b * 8] < t0)) t0 = st[(size_t)b * 8];
+    for (int half = 0; half < 2; ++half)
+      for (int i = 0; i < 5; ++i) {
+        double sum = 0, mx = 0, mn = 1e18; int c = 0;
+        for (int b = half * 272; b < (half ? 1024 : 272); ++b) { const long long* s = &st[(size_t)b * 8]; if (s[0] && s[i]) { double v = (s[i] - t0) / 100.0; sum += v; mx = std::max(mx, v); mn = std::min(mn, v); c++; } }
+        if (c) printf("   wgrad blocks %s stamp %d: min %6.2f mean %6.2f max %6.2f us (n=%d)\n", half ? ">=272" : "<272 ", i, mn, sum / c, mx, c);
+      }
   }
   return 0;
 }

@@ -17,6 +17,7 @@
 // i.e. 4 dependent launches instead of 10.  dgrad streams TRANSPOSED copies of W_1.. (WT_j [N_j][K_j]) so that its
 // weight stream is as coalesced as the forward pass's; a small launch refreshes them from the parameters.
 #include "dnn_shared.hpp"
+#include "optim_shared.hpp"
 
 namespace ultr {
 
@@ -30,6 +31,11 @@ __device__ long long g_tc_wstamps[1024 * 8 * 4];
   do {                                                                                                                \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_tc_wstamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (i)] = wall_clock64(); \
   } while (0)
+__device__ long long g_wg_stamps[1024 * 8];
+#define WG_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_stamps[blockIdx.x * 8 + (i)] = wall_clock64();         \
+  } while (0)
 #define TC_STAMP(i)                                                                                       \
   do {                                                                                                    \
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + (i)] = wall_clock64();       \
@@ -37,6 +43,7 @@ __device__ long long g_tc_wstamps[1024 * 8 * 4];
 #else
 #define TC_STAMP(i) do { } while (0)
 #define TC_WSTAMP(i) do { } while (0)
+#define WG_STAMP(i) do { } while (0)
 #endif
 
 struct TcArgs {
@@ -785,7 +792,8 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   if (warm == 1.2345e-30f && p.B < 0) p.outpart[0] = warm;  // never true: keeps the warm-up loads alive
 }
 
-// WT_j[n][k] = W_j[k][n] for the hidden layers j >= 1 (32 x 32 tiles through LDS), one launch for all of them
+// WT_j[n][k] = W_j[k][n] for the hidden layers j >= 1 (32 x 32 tiles through LDS), one launch for all of them: the
+// step's preparation launch when the caller's update call has not refreshed the copies (ultr_clip_adagrad_fused does).
 struct TransposeArgs {
   int n; const float* W[ULTR_MAX_LAYERS]; float* WT[ULTR_MAX_LAYERS]; int K[ULTR_MAX_LAYERS], N[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS];
   int start[ULTR_MAX_LAYERS + 1];
@@ -805,6 +813,104 @@ __global__ void __launch_bounds__(256) transpose_weights_kernel(TransposeArgs p)
     if (n0 + r < N && k0 + c < ldk) p.WT[j][(long long)(n0 + r) * ldk + k0 + c] = t[c][r];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradients through an LDS ring filled by LDS-DMA.
+//   G[k][n] = sum_m xhat[m][k] dz[m][n]  (+ S[n] = sum_m dz[m][n]),  64 x 64 outputs per workgroup (2 x 2 waves of
+//   32 x 32), rows split into slabs over the grid.
+// Both operands were written by the launch before: every first touch comes from the Infinity Cache / HBM at 1-2 us.
+// The register-streaming wgrad_body keeps two 32-row chunks in flight per wave and ran latency-bound (measured: 1.3 to
+// 1.5 us per chunk against 0.47 us of MFMA).  Here global_load_lds_dwordx4 moves the 32 x 64 tiles of both operands
+// into a ring of kWgStages slots without touching a register, kWgStages - 1 chunks ahead of the multiply, and the
+// waves wait with counted vmcnt: one raw barrier per chunk, no vmcnt(0) inside the loop.
+//   Rows beyond M: the operand buffers hold zero rows up to the next multiple of 32 (the fused plan pads them; the
+//   workspace is zero-initialised by the caller and nothing ever writes there), so no chunk needs a row mask.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWgStages = 4;
+constexpr int kWgTile = 32 * 64;               // floats per operand tile
+constexpr int kWgSlot = 2 * kWgTile;           // A then B
+constexpr size_t kWgRingBytes = sizeof(float) * kWgStages * kWgSlot;
+
+#define ULTR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int by, int bz, float* ring) {
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int k0 = by * 64, n0 = bz * 64;
+  const long long m_begin = (long long)bx * p.rows_per_split;
+  long long m_end = m_begin + p.rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int nch = (int)((m_end - m_begin + 31) >> 5);
+  // this wave's DMA pieces: rows 8 w .. 8 w + 7 of each tile, 4 rows (1 KB) per instruction; lane -> row lane / 16,
+  // 16 bytes at column 4 (lane % 16)
+  const int prow = 8 * w + (lane >> 4), pcol = 4 * (lane & 15);
+  const float* a_src = p.xhat + (m_begin + prow) * p.ldx + min(k0 + pcol, p.ldx - 4);
+  const float* b_src = p.dz + (m_begin + prow) * p.ldn + min(n0 + pcol, p.ldn - 4);
+  const size_t a_step = (size_t)32 * p.ldx, b_step = (size_t)32 * p.ldn;
+  const size_t a_row4 = (size_t)4 * p.ldx, b_row4 = (size_t)4 * p.ldn;
+  auto issue = [&](int c) {
+    if (c < nch) {  // wave-uniform
+      float* slot = ring + (c % kWgStages) * kWgSlot + 8 * w * 64;
+      const float* ap = a_src + (size_t)c * a_step;
+      const float* bp = b_src + (size_t)c * b_step;
+      __builtin_amdgcn_global_load_lds(ap, ULTR_LDS_PTR(slot), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(ap + a_row4, ULTR_LDS_PTR(slot + 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(bp, ULTR_LDS_PTR(slot + kWgTile), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(bp + b_row4, ULTR_LDS_PTR(slot + kWgTile + 256), 16, 0, 0);
+    }
+  };
+  WG_STAMP(0);
+#pragma unroll
+  for (int c = 0; c < kWgStages - 1; ++c) issue(c);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum = 0.f;
+  const bool do_colsum = by == 0 && wr == 0;
+  const int a_off = h * 64 + wr * 32 + l31, b_off = kWgTile + h * 64 + wc * 32 + l31;
+  for (int c = 0; c < nch; ++c) {
+    // chunk c has landed once at most `ahead` younger chunks (4 DMA each) are still in flight
+    const int ahead = min(kWgStages - 2, nch - 1 - c);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (c == 0) WG_STAMP(1);
+    if (c == 1) WG_STAMP(2);
+    issue(c + kWgStages - 1);  // into the slot of chunk c - 1: every wave has multiplied it out (the barrier above)
+    const float* slot = ring + (c % kWgStages) * kWgSlot;
+    float a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      a[t] = slot[a_off + 128 * t];
+      b[t] = slot[b_off + 128 * t];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    if (do_colsum) {
+      float s4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s4[q] = (b[4 * q] + b[4 * q + 1]) + (b[4 * q + 2] + b[4 * q + 3]);
+      colsum += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+  }
+  WG_STAMP(3);
+  float* gs = p.gslab + (long long)bx * p.K * p.ldn;
+  const int col = n0 + wc * 32 + l31;
+  if (col < p.ldn) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + wr * 32 + acc_row(r, h);
+      if (k < p.K) gs[(long long)k * p.ldn + col] = acc[r];
+    }
+  }
+  if (do_colsum) {
+    float other;
+    const float mine = xor32_partner(colsum, &other);  // the two wave halves hold alternate rows
+    if (h == 0 && col < p.ldn) p.sslab[(long long)bx * p.ldn + col] = mine + other;
+  }
+  WG_STAMP(4);
+}
+
 // Every layer's weight-gradient GEMM in one launch, with the loss statistics and the in-step metrics as rider
 // workgroups (they come first: the longer poles).
 struct WgradAllArgs {
@@ -815,6 +921,7 @@ struct WgradAllArgs {
   int ride; DlaArgs dla; IpwArgs ipw; RemArgs rem; PdArgs pd; int l_blocks, l_pad;
 };
 __global__ void __launch_bounds__(kThreads, 2) wgrad_all_kernel(WgradAllArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];
   int id = blockIdx.x;
   if (id < p.m_pad) {
     if (id >= p.m_blocks) return;
@@ -841,7 +948,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_all_kernel(WgradAllArgs p) 
   while (j + 1 < p.n_layers && id >= p.start[j + 1]) ++j;
   const int local = id - p.start[j];
   const int bx = local % p.nsplit, t = local / p.nsplit;
-  wgrad_body(p.g[j], bx, t % p.gy[j], t / p.gy[j]);
+  wgrad_lds_body(p.g[j], bx, t % p.gy[j], t / p.gy[j], ring);
 }
 
 __global__ void __launch_bounds__(kThreads) finalize_fused_kernel(FinalizeRiderArgs p) {
@@ -913,9 +1020,10 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   if (ns > cdiv(M, 64)) ns = cdiv(M, 64);
   P.rows_per_split = (int)(cdiv(cdiv(M, ns), 32) * 32);
   P.nsplit = (int)cdiv(M, P.rows_per_split);
+  const long long Mpad = (M + 31) & ~31ll;  // zero rows up to a whole 32-row chunk (wgrad_lds_body)
   for (int j = 0; j < P.H; ++j) {
-    P.xhat[j] = take(M * round4(P.K[j]));
-    P.dz[j] = take(M * P.ldn[j]);
+    P.xhat[j] = take(Mpad * round4(P.K[j]));
+    P.dz[j] = take(Mpad * P.ldn[j]);
     P.wt[j] = j >= 1 ? take((long long)P.N[j] * round4(P.K[j])) : 0;
     P.gslab[j] = take((long long)P.nsplit * P.K[j] * P.ldn[j]);
     P.sslab[j] = take((long long)P.nsplit * P.ldn[j]);
@@ -931,6 +1039,12 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
 using namespace ultr;
 
 #ifdef ULTR_STAMPS
+extern "C" int ultr_debug_wg_stamps(long long* host, int n) {
+  if (n > 1024 * 8) n = 1024 * 8;
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), sizeof(long long) * (size_t)n);
+  return n;
+}
 extern "C" int ultr_debug_tc_wstamps(long long* host, int n) {
   if (n > 1024 * 32) n = 1024 * 32;
   hipDeviceSynchronize();
@@ -986,7 +1100,8 @@ static int launch_chain(const TcArgs& a, int nwg, size_t smem, bool fast, hipStr
 
 extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params, const float* table,
                                     const float* table_stats, int n_rows, int ldx, const int* docids, int B, int L,
-                                    void* workspace, float* scores, float* grads, float* sumsq, void* stream) {
+                                    void* workspace, int wt_fresh, float* scores, float* grads, float* sumsq,
+                                    void* stream) {
   const long long M = (long long)B * L;
   int rc = ultr_common_checks("ultr_dnn_train_fused", desc, params, table, table_stats, n_rows, ldx, docids, M, workspace);
   if (rc) return rc;
@@ -1009,8 +1124,8 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   hipStream_t st = as_stream(stream);
   const int H = P.H;
 
-  // ---- transposed weights for the dgrad GEMMs
-  if (H >= 2) {
+  // ---- transposed weights for the dgrad GEMMs, unless the caller's last update call left them current
+  if (H >= 2 && !wt_fresh) {
     TransposeArgs t{};
     t.n = H - 1;
     int start = 0;
@@ -1090,10 +1205,22 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
     // the chain kernel has written the list weights: the riders must not race with the metrics that read them
     g.dla.list_weights = nullptr; g.ipw.list_weights = nullptr; g.rem.list_weights = nullptr;
     g.l_blocks = (int)pl.nblocks; g.l_pad = (g.l_blocks + 7) & ~7;
+#ifdef ULTR_STAMPS
+    { const char* e = getenv("ULTR_WG_DBG"); if (e && (atoi(e) & 1)) g.l_blocks = 0; }
+#endif
+    static bool wg_attr = false;
+    if (!wg_attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kWgRingBytes) != hipSuccess) {
+        set_error("ultr_dnn_train_fused: cannot raise the dynamic LDS limit");
+        return ULTR_EHIP;
+      }
+      wg_attr = true;
+    }
     {
       ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_all_kernel/P%lld", [&] {
         long long s = 0; for (int j = 0; j < H; ++j) s += (long long)P.K[j] * P.N[j]; return s; }()) : "wgrad_all_kernel", st);
-      hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)(start + g.m_pad + g.l_pad)), dim3(kThreads), 0, st, g);
+      hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)(start + g.m_pad + g.l_pad)), dim3(kThreads), kWgRingBytes, st, g);
     }
     rc = check_launch("wgrad_all_kernel");
     if (rc) return rc;
@@ -1129,4 +1256,32 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
     hipLaunchKernelGGL(finalize_fused_kernel, dim3(fblocks + (unsigned)fr.a_pad), dim3(kThreads), 0, st, fr);
   }
   return check_launch("finalize_fused_kernel");
+}
+
+extern "C" int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, void* workspace, float* theta, float* acc,
+                                       const float* grads, long long n, const float* denom, float scale_const, float l2,
+                                       float clip_norm, float lr, int strategy, float* out_norm, float* ws, float* theta_s,
+                                       float* acc_s, const float* grads_s, int n_s, const float* denom_s,
+                                       float scale_const_s, float l2_s, float clip_norm_s, float lr_s, float* out_norm_s,
+                                       const float* sumsq, int n_sumsq, long long n_covered, const float* publish_src,
+                                       float* publish_dst, int publish_n, void* stream) {
+  int rc = ultr_check_desc(desc, "ultr_clip_adagrad_fused");
+  if (rc) return rc;
+  const FusedPlan P = make_fused_plan(desc, B, L);
+  ULTR_REQUIRE(P.ok && workspace, ULTR_EINVAL, "ultr_clip_adagrad_fused: shape not supported by the fused step, or no workspace");
+  ULTR_REQUIRE(n >= desc->n_params && n > 4096, ULTR_EINVAL, "ultr_clip_adagrad_fused: theta must cover the scorer's parameters");
+  SmallGroup r{};
+  if (theta_s) {
+    ULTR_REQUIRE(grads_s && n_s > 0 && n_s <= 4096, ULTR_EINVAL, "ultr_clip_adagrad_fused: small group needs 1..4096 parameters");
+    ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc_s, ULTR_EINVAL, "ultr_clip_adagrad_fused: Adagrad needs an accumulator");
+    r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
+  }
+  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}};
+  float* wsf = reinterpret_cast<float*>(workspace);
+  for (int j = 1; j < P.H; ++j) {
+    const int t = o.tr.n++;
+    o.tr.off[t] = desc->off_W[j]; o.tr.K[t] = P.K[j]; o.tr.N[t] = P.N[j]; o.tr.ldn[t] = P.ldn[j];
+    o.tr.dst[t] = wsf + P.wt[j];
+  }
+  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream);
 }

@@ -6,7 +6,7 @@
 //
 // HBM-bound: 20 B per parameter per step (read g, acc, theta; write acc, theta) + 8 B for the
 // norm pass (g, theta re-read, L2-resident for the DNN's <= 2 MB of parameters).
-#include "common.hpp"
+#include "optim_shared.hpp"
 
 namespace ultr {
 
@@ -17,11 +17,6 @@ __device__ __forceinline__ float eff_scale(const float* denom, float scale_const
   return denom ? scale_const / denom[0] : scale_const;
 }
 
-// A small parameter group (DLA's propensity tower: L+1 floats): norm, clip and update by ONE workgroup.
-struct SmallGroup {
-  float* theta; float* accum; const float* grads; int n; const float* denom;
-  float scale_const, l2, clip_norm, lr; int strategy; float* out_norm;
-};
 __device__ __forceinline__ void clip_adagrad_small(float* theta, float* accum, const float* grads, int n,
                                                    const float* denom, float scale_const, float l2, float clip_norm,
                                                    float lr, int strategy, float* out_norm) {
@@ -78,12 +73,6 @@ __global__ void __launch_bounds__(kOptThreads) gnorm_partial_kernel(const float*
   block_sum<1>(acc, red);
   if (threadIdx.x == 0) ws[8 + blockIdx.x] = acc[0];
 }
-
-// Options of the fused optimiser tail (ultr_clip_adagrad3); all nullable.
-struct TailOpts {
-  const float* sumsq; int n_sumsq; long long n_covered;  // sum-of-squares partials of grads[0, n_covered) (raw, l2 == 0)
-  const float* pub_src; float* pub_dst; int pub_n;       // results row copied out (pinned host memory) by workgroup 0
-};
 
 __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __restrict__ theta, float* __restrict__ accum,
                                                                     const float* __restrict__ grads, long long n,
@@ -158,6 +147,20 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
       for (int q = 0; q < 4; ++q) tv[q] -= lr * (gv[q] * sc + l2 * tv[q]) * f;
     }
     t4[i] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+    if (o.tr.n > 0) {  // the updated values of a weight matrix also go to its transposed copy
+      const long long e = i << 2;
+#pragma unroll 1
+      for (int j = 0; j < o.tr.n; ++j) {
+        const long long rel = e - o.tr.off[j];
+        if (rel >= 0 && rel < (long long)o.tr.K[j] * o.tr.ldn[j]) {
+          const int k = (int)(rel / o.tr.ldn[j]), n0 = (int)(rel - (long long)k * o.tr.ldn[j]);  // ldn % 4 == 0: one row
+          const int ldk = (o.tr.K[j] + 3) & ~3;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n0 + q < o.tr.N[j]) o.tr.dst[j][(long long)(n0 + q) * ldk + k] = tv[q];
+        }
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
@@ -184,15 +187,16 @@ __global__ void __launch_bounds__(kOptThreads) clip_adagrad_small_kernel(float* 
 
 using namespace ultr;
 
-static int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom,
-                             float scale_const, float l2, float clip_norm, float lr, int strategy, float* out_norm,
-                             float* ws, const SmallGroup& rider, TailOpts o, void* stream) {
+namespace ultr {
+int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom,
+                      float scale_const, float l2, float clip_norm, float lr, int strategy, float* out_norm,
+                      float* ws, const SmallGroup& rider, TailOpts o, void* stream) {
   ULTR_REQUIRE(theta && grads && n > 0, ULTR_EINVAL, "ultr_clip_adagrad: bad argument");
   ULTR_REQUIRE(strategy == ULTR_OPT_ADAGRAD || strategy == ULTR_OPT_SGD, ULTR_EINVAL,
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
   if (n <= 4096) {
-    ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0, ULTR_EINVAL,
+    ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0 && o.tr.n == 0, ULTR_EINVAL,
                  "ultr_clip_adagrad: the fused options need a main group of more than 4096 parameters");
     {
       ultr::ProfScope prof_("clip_adagrad_small_kernel", as_stream(stream));
@@ -230,6 +234,7 @@ static int clip_adagrad_impl(float* theta, float* acc, const float* grads, long 
   }
   return check_launch("adagrad_apply_kernel");
 }
+}  // namespace ultr
 
 extern "C" int ultr_clip_adagrad(float* theta, float* acc, const float* grads, long long n, const float* denom,
                                  float scale_const, float l2, float clip_norm, float lr, int strategy,
@@ -261,6 +266,6 @@ extern "C" int ultr_clip_adagrad3(float* theta, float* acc, const float* grads, 
     ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc_s, ULTR_EINVAL, "ultr_clip_adagrad3: Adagrad needs an accumulator");
     r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
   }
-  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n};
+  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}};
   return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream);
 }

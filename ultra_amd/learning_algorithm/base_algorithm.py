@@ -277,7 +277,8 @@ class BaseAlgorithm(ABC):
         straight into the pinned host slot by the update launch."""
         if not self.fused_tail:
             return None
-        tail = {'sumsq': tb['sumsq'] if tb.get('sumsq_valid') else None, 'n_covered': self.n_params}
+        tail = {'sumsq': tb['sumsq'] if tb.get('sumsq_valid') else None, 'n_covered': self.n_params,
+                'fused': self.model.fused_update_target() if tb.get('fused') else None}
         if tb['host_dev'] is None:
             base = _lib.host_device_ptr(tb['host'])
             tb['host_dev'] = base.value if base is not None else 0
@@ -324,7 +325,8 @@ class BaseAlgorithm(ABC):
         L = self.rank_list_size
         batch = self._to_device_batch(input_feed, L)
         tb = self._train_buffers(batch.B)
-        if self._fused_ok(batch):
+        tb['fused'] = self._fused_ok(batch)
+        if tb['fused']:
             self._step_local_fused(tb, batch)
             self._pending = (tb, batch)
             return
@@ -476,6 +478,22 @@ class BaseAlgorithm(ABC):
         if sumsq is not None and (gr.data_ptr() != self._train_bufs['grads'].data_ptr() or n < tail['n_covered']):
             sumsq = None  # the partials describe the step's flat gradient buffer only
         pub = tail.get('pub')
+        fused = tail.get('fused')
+        if fused is not None and th.data_ptr() == self.model.params.data_ptr():
+            B, L, ws = fused  # the scorer's update also refreshes the fused step's transposed weight copies
+            _lib.check(_lib.lib().ultr_clip_adagrad_fused(
+                self.model.desc, B, L, _lib.ptr(ws),
+                _lib.ptr(th), _lib.ptr(ac), _lib.ptr(gr), int(n), _lib.ptr(den), float(sc), float(l2), float(clip), float(lr),
+                self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
+                _lib.ptr(ths), _lib.ptr(acs), _lib.ptr(grs), int(ns or 0), _lib.ptr(dens), float(scs), float(l2s), float(clips),
+                float(lrs), _lib.ptr(outs),
+                _lib.ptr(sumsq), int(sumsq.numel()) if sumsq is not None else 0, int(tail['n_covered']),
+                _lib.ptr(pub[0]) if pub else None, ctypes.c_void_p(pub[1]) if pub else None, int(pub[2]) if pub else 0,
+                _lib.current_stream()), 'ultr_clip_adagrad_fused')
+            self.model.mark_wt_fresh(ws)
+            if pub:
+                tail['published'] = True
+            return
         _lib.check(_lib.lib().ultr_clip_adagrad3(
             _lib.ptr(th), _lib.ptr(ac), _lib.ptr(gr), int(n), _lib.ptr(den), float(sc), float(l2), float(clip), float(lr),
             self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),

@@ -40,6 +40,8 @@ class DNN(BaseRankingModel):
         self.params = None
         self._ws = {}
         self._last = None
+        self._last_fused = None
+        self._wt_state = None
 
     # ---- variables -------------------------------------------------------------------------
     def layer_shapes(self, feature_size):
@@ -211,11 +213,22 @@ class DNN(BaseRankingModel):
         grads[:n_params] are written (``ultr_dnn_train_fused``)."""
         L, B = docids_lb.shape
         ws = self._fused_workspace(B, L)
+        # the workspace's transposed weight copies are current iff the last writer of the parameters was the update
+        # call that refreshed them (torch bumps the version counter on every in-place write of its own)
+        fresh = self._wt_state == (ws.data_ptr(), self.params._version)
         _lib.check(_lib.lib().ultr_dnn_train_fused(
             self.desc, _lib.ptr(self.params), _lib.ptr(table), _lib.ptr(table_stats), int(n_rows), int(table.stride(0)),
-            _lib.ptr(docids_lb), int(B), int(L), _lib.ptr(ws), _lib.ptr(scores), _lib.ptr(grads), _lib.ptr(sumsq),
-            _lib.current_stream()), 'ultr_dnn_train_fused')
+            _lib.ptr(docids_lb), int(B), int(L), _lib.ptr(ws), 1 if fresh else 0, _lib.ptr(scores), _lib.ptr(grads),
+            _lib.ptr(sumsq), _lib.current_stream()), 'ultr_dnn_train_fused')
+        self._last_fused = (int(B), int(L), ws)
         return scores
+
+    def fused_update_target(self):
+        """(B, L, workspace) of the last fused step: the update call refreshes the transposed weights there."""
+        return self._last_fused
+
+    def mark_wt_fresh(self, ws):
+        self._wt_state = (ws.data_ptr(), self.params._version)
 
     def sumsq_count(self):
         return int(_lib.lib().ultr_dnn_sumsq_count(self.desc))
