@@ -170,6 +170,13 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& p, const int b
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < 3 * K + 1) {
       int b = g;
+      for (; b + 60 < p.out_blocks; b += 64) {  // 16 independent loads in flight per thread (one round trip each round)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = p.outpart[(long long)(b + 4 * q) * (3 * K + 4) + i];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a4[q & 3] += v[q];
+      }
       for (; b + 12 < p.out_blocks; b += 16) {  // 4 independent loads in flight per thread
 #pragma unroll
         for (int q = 0; q < 4; ++q) a4[q] += p.outpart[(long long)(b + 4 * q) * (3 * K + 4) + i];

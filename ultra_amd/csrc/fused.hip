@@ -911,17 +911,33 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int b
   WG_STAMP(4);
 }
 
-// Every layer's weight-gradient GEMM in one launch, with the loss statistics and the in-step metrics as rider
-// workgroups (they come first: the longer poles).
+// Every layer's weight-gradient GEMM in one launch: exactly the workgroups that fit the chip at once (two per CU).
 struct WgradAllArgs {
   int n_layers, nsplit;
   WgradArgs g[ULTR_MAX_LAYERS];
   int start[ULTR_MAX_LAYERS + 1], gy[ULTR_MAX_LAYERS];
-  MetricsArgs m; int m_blocks, m_pad;
-  int ride; DlaArgs dla; IpwArgs ipw; RemArgs rem; PdArgs pd; int l_blocks, l_pad;
 };
 __global__ void __launch_bounds__(kThreads, 2) wgrad_all_kernel(WgradAllArgs p) {
   extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int id = blockIdx.x;
+  int j = 0;
+  while (j + 1 < p.n_layers && id >= p.start[j + 1]) ++j;
+  const int local = id - p.start[j];
+  const int bx = local % p.nsplit, t = local / p.nsplit;
+  wgrad_lds_body(p.g[j], bx, t % p.gy[j], t / p.gy[j], ring);
+}
+
+// The slab reduction, with the step's latency-bound side jobs as rider workgroups (they come first): the in-step
+// metrics, the loss statistics (both need only scores / clicks / list weights, which the chain kernel left two
+// launches ago, and feed nothing before the update launch).  The reduction's own workgroups are short and leave most
+// of the chip's workgroup slots free.  (The assembly of the NEXT batch overwrites what these riders read: it rides
+// one launch later, with the update.)
+struct FinalizeFusedArgs {
+  FinalizeArgs f;
+  MetricsArgs m; int m_blocks, m_pad;
+  int ride; DlaArgs dla; IpwArgs ipw; RemArgs rem; PdArgs pd; int l_blocks, l_pad;
+};
+__global__ void __launch_bounds__(kThreads) finalize_fused_kernel(FinalizeFusedArgs p) {
   int id = blockIdx.x;
   if (id < p.m_pad) {
     if (id >= p.m_blocks) return;
@@ -943,21 +959,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_all_kernel(WgradAllArgs p) 
     if (p.ride == ULTR_RIDE_PD) pd_loss_small_body(p.pd, id, p.l_blocks, s_acc, s_part, s_tower);
     return;
   }
-  id -= p.l_pad;
-  int j = 0;
-  while (j + 1 < p.n_layers && id >= p.start[j + 1]) ++j;
-  const int local = id - p.start[j];
-  const int bx = local % p.nsplit, t = local / p.nsplit;
-  wgrad_lds_body(p.g[j], bx, t % p.gy[j], t / p.gy[j], ring);
-}
-
-__global__ void __launch_bounds__(kThreads) finalize_fused_kernel(FinalizeRiderArgs p) {
-  const int id = blockIdx.x;
-  if (id >= p.a_pad) {
-    finalize_body(p.f, id - p.a_pad);
-    return;
-  }
-  if (id < p.a_blocks) assemble_slots_body(p.a, id, p.a_blocks);
+  finalize_body(p.f, id - p.l_pad);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1015,7 +1017,8 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   };
   long long tiles = 0;
   for (int j = 0; j < P.H; ++j) tiles += cdiv(P.K[j], 64) * cdiv(P.N[j], 64);
-  long long ns = 512 / tiles;
+  static const int wg_target = [] { const char* e = getenv("ULTR_WG_TARGET"); return e ? atoi(e) : 512; }();
+  long long ns = wg_target / tiles;
   if (ns < 1) ns = 1;
   if (ns > cdiv(M, 64)) ns = cdiv(M, 64);
   P.rows_per_split = (int)(cdiv(cdiv(M, ns), 32) * 32);
@@ -1192,22 +1195,6 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
       start += P.nsplit * g.gy[j] * (int)cdiv(P.ldn[j], 64);
     }
     g.start[H] = start;
-    if (g_pending_metrics.on && g_pending_metrics.nblocks > 64) {  // too big to ride along: a launch of its own
-      g_pending_metrics.on = false;
-      rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, st);
-      if (rc) return rc;
-    }
-    if (g_pending_metrics.on) {
-      g.m = g_pending_metrics.a; g.m_blocks = (int)g_pending_metrics.nblocks; g.m_pad = (g.m_blocks + 7) & ~7;
-      g_pending_metrics.on = false;
-    }
-    g.ride = pl.kind; g.dla = pl.dla; g.ipw = pl.ipw; g.rem = pl.rem; g.pd = pl.pd;
-    // the chain kernel has written the list weights: the riders must not race with the metrics that read them
-    g.dla.list_weights = nullptr; g.ipw.list_weights = nullptr; g.rem.list_weights = nullptr;
-    g.l_blocks = (int)pl.nblocks; g.l_pad = (g.l_blocks + 7) & ~7;
-#ifdef ULTR_STAMPS
-    { const char* e = getenv("ULTR_WG_DBG"); if (e && (atoi(e) & 1)) g.l_blocks = 0; }
-#endif
     static bool wg_attr = false;
     if (!wg_attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1220,14 +1207,14 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
     {
       ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_all_kernel/P%lld", [&] {
         long long s = 0; for (int j = 0; j < H; ++j) s += (long long)P.K[j] * P.N[j]; return s; }()) : "wgrad_all_kernel", st);
-      hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)(start + g.m_pad + g.l_pad)), dim3(kThreads), kWgRingBytes, st, g);
+      hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)start), dim3(kThreads), kWgRingBytes, st, g);
     }
     rc = check_launch("wgrad_all_kernel");
     if (rc) return rc;
   }
 
-  // ---- slab reduction -> flat gradient (+ the next batch's assembly)
-  FinalizeRiderArgs fr{};
+  // ---- slab reduction -> flat gradient, with the side jobs riding along
+  FinalizeFusedArgs fr{};
   FinalizeArgs& f = fr.f;
   f.H = H;
   int start = 0;
@@ -1246,14 +1233,24 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   f.outpart = ws + P.outpart; f.out_blocks = P.nwg; f.Kout = P.K[H];
   f.sumsq = sumsq;
   const unsigned fblocks = (unsigned)(start + (3 * P.K[H] + 1 + 63) / 64);
-  if (g_pending_assemble.on && g_pending_assemble.nblocks <= 4096) {
-    fr.a = g_pending_assemble.a;
-    fr.a_blocks = (int)g_pending_assemble.nblocks; fr.a_pad = (fr.a_blocks + 7) & ~7;
-    g_pending_assemble.on = false;
+  if (g_pending_metrics.on && g_pending_metrics.nblocks > 64) {  // too big to ride along: a launch of its own
+    g_pending_metrics.on = false;
+    rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, st);
+    if (rc) return rc;
   }
+  if (g_pending_metrics.on) {
+    fr.m = g_pending_metrics.a; fr.m_blocks = (int)g_pending_metrics.nblocks; fr.m_pad = (fr.m_blocks + 7) & ~7;
+    g_pending_metrics.on = false;
+  }
+  fr.ride = pl.kind; fr.dla = pl.dla; fr.ipw = pl.ipw; fr.rem = pl.rem; fr.pd = pl.pd;
+  // the chain kernel has written the list weights: the loss rider must not race with the metrics that read them
+  fr.dla.list_weights = nullptr; fr.ipw.list_weights = nullptr; fr.rem.list_weights = nullptr;
+  fr.l_blocks = (int)pl.nblocks; fr.l_pad = (fr.l_blocks + 7) & ~7;
+  // (a parked batch assembly stays parked: it rides with the update launch, ultr_clip_adagrad_fused -- this launch's
+  // riders still read the current batch, which the assembly overwrites)
   {
     ultr::ProfScope prof_("finalize_fused_kernel", st);
-    hipLaunchKernelGGL(finalize_fused_kernel, dim3(fblocks + (unsigned)fr.a_pad), dim3(kThreads), 0, st, fr);
+    hipLaunchKernelGGL(finalize_fused_kernel, dim3(fblocks + (unsigned)(fr.m_pad + fr.l_pad)), dim3(kThreads), 0, st, fr);
   }
   return check_launch("finalize_fused_kernel");
 }
@@ -1276,7 +1273,12 @@ extern "C" int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, vo
     ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc_s, ULTR_EINVAL, "ultr_clip_adagrad_fused: Adagrad needs an accumulator");
     r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
   }
-  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}};
+  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}, AssembleArgs{}, 0, 0};
+  if (g_pending_assemble.on && g_pending_assemble.nblocks <= 4096) {  // the next batch's assembly rides with the update
+    o.a = g_pending_assemble.a;
+    o.a_blocks = (int)g_pending_assemble.nblocks; o.a_pad = (o.a_blocks + 7) & ~7;
+    g_pending_assemble.on = false;
+  }
   float* wsf = reinterpret_cast<float*>(workspace);
   for (int j = 1; j < P.H; ++j) {
     const int t = o.tr.n++;

@@ -82,7 +82,12 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
                                                                     const float* __restrict__ ws, TailOpts o,
                                                                     SmallGroup rider) {
   __shared__ float red[4];
-  if (rider.n > 0 && blockIdx.x == gridDim.x - 1) {  // the extra block updates the small group completely
+  if ((int)blockIdx.x < o.a_pad) {  // the next batch's assembly rides along (the longer pole: first)
+    if ((int)blockIdx.x < o.a_blocks) assemble_slots_body(o.a, blockIdx.x, o.a_blocks);
+    return;
+  }
+  const unsigned int bid = blockIdx.x - o.a_pad, nbid = gridDim.x - o.a_pad;
+  if (rider.n > 0 && bid == nbid - 1) {  // the extra block updates the small group completely
     clip_adagrad_small(rider.theta, rider.accum, rider.grads, rider.n, rider.denom, rider.scale_const, rider.l2,
                        rider.clip_norm, rider.lr, rider.strategy, rider.out_norm);
     // its norm goes out directly: workgroup 0 publishes the row at the same time and skips this entry
@@ -91,14 +96,14 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
     return;
   }
   const float sc = eff_scale(denom, scale_const);
-  const long long nblk = gridDim.x - (rider.n > 0 ? 1 : 0);
+  const long long nblk = nbid - (rider.n > 0 ? 1 : 0);
   // The block's first (usually only) batch of gradient / parameter / accumulator values is requested before the norm
   // is formed: the update needs the norm, its operands do not, and the two memory round trips overlap.
   const long long n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(grads);
   float4* t4 = reinterpret_cast<float4*>(theta);
   float4* a4 = reinterpret_cast<float4*>(accum);
-  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i0 = (long long)bid * blockDim.x + threadIdx.x;
   float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), t0 = g0, a0 = g0;
   if (i0 < n4) {
     g0 = g4[i0];
@@ -118,8 +123,8 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
     block_sum<1>(ssq, red);
     nrm = sqrtf(ssq[0]);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
-  if (blockIdx.x == 0 && o.pub_n > 0) {  // the step's results row, straight into the caller's (pinned host) buffer
+  if (bid == 0 && threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
+  if (bid == 0 && o.pub_n > 0) {  // the step's results row, straight into the caller's (pinned host) buffer
     for (int i = threadIdx.x; i < o.pub_n; i += blockDim.x) {
       const float* src = o.pub_src + i;
       if (rider.n > 0 && src == rider.out_norm) continue;
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+  if (bid == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
     const float gq = (grads[i] * sc + l2 * theta[i]) * f;
     if (strategy == ULTR_OPT_ADAGRAD) {
@@ -196,7 +201,7 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
   if (n <= 4096) {
-    ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0 && o.tr.n == 0, ULTR_EINVAL,
+    ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0 && o.tr.n == 0 && o.a_blocks == 0, ULTR_EINVAL,
                  "ultr_clip_adagrad: the fused options need a main group of more than 4096 parameters");
     {
       ultr::ProfScope prof_("clip_adagrad_small_kernel", as_stream(stream));
@@ -228,7 +233,7 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
   const SmallGroup& apply_rider = o.sumsq ? rider : none;  // no norm launch: the small group rides with the update
   {
     ultr::ProfScope prof_("adagrad_apply_kernel", as_stream(stream));
-    hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)(blocks + (apply_rider.n > 0 ? 1 : 0))), dim3(kOptThreads), 0,
+    hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)(blocks + (apply_rider.n > 0 ? 1 : 0) + o.a_pad)), dim3(kOptThreads), 0,
                      as_stream(stream), theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, (int)blocks,
                      out_norm, ws, o, apply_rider);
   }
@@ -266,6 +271,6 @@ extern "C" int ultr_clip_adagrad3(float* theta, float* acc, const float* grads, 
     ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc_s, ULTR_EINVAL, "ultr_clip_adagrad3: Adagrad needs an accumulator");
     r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
   }
-  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}};
+  TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}, AssembleArgs{}, 0, 0};
   return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream);
 }

@@ -1,6 +1,6 @@
 // Optimiser types shared by optim.hip and fused.hip (the fused step's update call also refreshes the transposed weights).
 #pragma once
-#include "common.hpp"
+#include "feed_body.hpp"
 
 namespace ultr {
 
@@ -23,6 +23,9 @@ struct TailOpts {
   const float* sumsq; int n_sumsq; long long n_covered;  // sum-of-squares partials of grads[0, n_covered) (raw, l2 == 0)
   const float* pub_src; float* pub_dst; int pub_n;       // results row copied out (pinned host memory) by workgroup 0
   TransposeOpts tr;                                      // tr.n > 0: transposed copies of updated weight matrices
+  // a_blocks > 0: the assembly of the NEXT batch rides with the update launch as its first a_pad workgroups (nothing
+  // reads the current batch any more, so it may land in the same buffers; ultr_batch_assemble_deferred)
+  AssembleArgs a; int a_blocks, a_pad;
 };
 
 int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom, float scale_const,
