@@ -164,6 +164,7 @@ __device__ __forceinline__ bool last_block_arrive(unsigned int* counter, unsigne
 // loads at a time, and the RG partials of a column meet in LDS in fixed order.  A thread that walks the rows of
 // its column alone pays one L2 round trip per row (~0.3 us each: measured 5 us for 16 rows, tools/fenceprobe.hip).
 // s_tmp: blockDim.x floats of LDS; the totals land in s_out[0..ns).  Requires ns <= blockDim.x.
+template <bool SC1 = false>
 __device__ __forceinline__ void reduce_rows(const float* __restrict__ rows, int G, int ns, int max_from, float* s_tmp,
                                             float* s_out) {
   const int NT = blockDim.x, RG = NT / ns;
@@ -174,7 +175,10 @@ __device__ __forceinline__ void reduce_rows(const float* __restrict__ rows, int 
     for (int b0 = rg; b0 < G; b0 += 4 * RG) {
       float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = rows[(long long)min(b0 + u * RG, G - 1) * ns + s];
+      for (int u = 0; u < 4; ++u) {
+        const float* src = rows + (long long)min(b0 + u * RG, G - 1) * ns + s;
+        v[u] = SC1 ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (b0 + u * RG < G) acc = is_max ? fmaxf(acc, v[u]) : acc + v[u];

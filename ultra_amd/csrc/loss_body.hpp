@@ -39,20 +39,25 @@ struct BlockStats {
 // totals also left in s_acc.
 __device__ __forceinline__ bool finish_stats(float* s_acc, int ns, int max_from, float* ws, float* out, unsigned int bid,
                                              unsigned int nb) {
+  // The hand-off to the last block carries no cache maintenance: every word of the partial rows is written with an
+  // agent-scope (sc1, write-through) store and read with an agent-scope load, the storing waves drain their stores
+  // before the workgroup barrier that precedes the counter's atomic add, and the last block loads only after its own
+  // add has returned.  The fenced form (buffer_wbl2 + buffer_inv) costs 3-4 us here, more while other workgroups of
+  // the launch keep the L2 dirty.
   unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
   float* rows = ws + 8;
   __syncthreads();
-  for (int s = threadIdx.x; s < ns; s += blockDim.x) rows[(long long)bid * ns + s] = s_acc[s];
-  const bool last = last_block_arrive(counter, nb);
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) st_agent(rows + (long long)bid * ns + s, s_acc[s]);
+  const bool last = last_block_arrive_sc1(counter, nb);
   if (last) {
     __shared__ float s_tmp[kLossThreads];
     if (ns <= (int)blockDim.x) {
-      reduce_rows(rows, (int)nb, ns, max_from, s_tmp, s_acc);
+      reduce_rows<true>(rows, (int)nb, ns, max_from, s_tmp, s_acc);
     } else {  // rows wider than the block (L = 64 with the widest statistics): plain column walk
       for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-        float r = rows[s];
+        float r = ld_agent(rows + s);
         for (unsigned int b = 1; b < nb; ++b) {
-          const float v = rows[(long long)b * ns + s];
+          const float v = ld_agent(rows + (long long)b * ns + s);
           r = (s >= max_from) ? fmaxf(r, v) : r + v;
         }
         s_acc[s] = r;

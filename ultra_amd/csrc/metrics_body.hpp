@@ -205,10 +205,11 @@ __device__ __forceinline__ void metrics_finish(const MetricsArgs& a, int bid, in
   unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
   float* rows = ws + 8;
   __syncthreads();
-  if (tid < nout) rows[(long long)bid * nout + tid] = s_acc[tid];
-  if (last_block_arrive(counter, nb)) {
+  // hand-off without cache maintenance: agent-scope stores and loads around an atomic arrival counter (loss_body.hpp)
+  if (tid < nout) st_agent(rows + (long long)bid * nout + tid, s_acc[tid]);
+  if (last_block_arrive_sc1(counter, nb)) {
     __shared__ float s_tmp[kMetThreads];
-    reduce_rows(rows, (int)nb, nout, 1 << 30, s_tmp, s_acc);
+    reduce_rows<true>(rows, (int)nb, nout, 1 << 30, s_tmp, s_acc);
     if (tid < nout && ((tid & 1) == 0 || list_weights)) out[tid] = s_acc[tid] / (float)B;
   }
 }
