@@ -360,6 +360,18 @@ int ultr_metrics_deferred(const float* scores, const float* labels, const int* d
 int ultr_metrics_flush(void* stream);
 /* Drop a parked request without running it (the scores it describes never came to be); returns 1 if there was one. */
 int ultr_metrics_cancel(void);
+/* ultr_metrics for callers that cannot allocate and own no workspace.  It has no counterpart in the reference: it is
+ * for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments and
+ * results as ultr_metrics minus `ws`: the partial rows and the arrival counter live in a device array inside the
+ * library (ultr_metrics_static_max_floats() floats = 1 MiB, held by every GPU the library runs on until the process
+ * ends); its address is looked up once per device.  The call makes no hipMalloc / hipFree and no allocating library
+ * call.  ULTR_ELIMIT when ultr_metrics_workspace_floats(B, n_topn) exceeds the array.  Every call on a GPU shares
+ * that GPU's array: two calls that overlap on one GPU (different streams, different threads) race -- serialise them
+ * or use ultr_metrics with workspaces of your own. */
+long long ultr_metrics_static_max_floats(void);
+int ultr_metrics_static(const float* scores, const float* labels, const int* docids, int n_rows,
+                        const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
+                        int n_topn, int metric_mask, float max_label, float* out, void* stream);
 /* The permutation itself: perm [B][topn] int32 = sort_by_scores(scores) indices. */
 int ultr_sort_by_scores(const float* scores, const float* u, int B, int Lx, int topn, int* perm,
                         void* stream);

@@ -7,6 +7,7 @@
 // first), which is exactly a sort by the total order (score desc, uniform asc, index asc); a
 // bitonic network under that comparator therefore yields the reference permutation bit for bit.
 #include "metrics_body.hpp"
+#include <mutex>
 
 namespace ultr {
 
@@ -289,6 +290,58 @@ extern "C" int ultr_metrics(const float* scores, const float* labels, const int*
   const int rc = prepare_metrics("ultr_metrics", scores, labels, docids, n_rows, list_weights, u_pred, B, Lx, topn_h,
                                  n_topn, metric_mask, max_label, out, ws, &a, &nblocks);
   if (rc) return rc;
+  return launch_metrics_now(a, nblocks, as_stream(stream));
+}
+
+// ---- the entry point that allocates nothing ------------------------------------------------------------------------
+// For callers that cannot allocate device memory (HIP graph capture, serving loops, harnesses that forbid hipMalloc)
+// and do not own a workspace: the partial rows and the arrival counter of metrics_kernel live in a file-scope device
+// array.  Every GPU the library runs on holds its own copy of the array at its own address until the process ends;
+// the address is looked up once per device and only that pointer is ever handed to a kernel or a memset.
+namespace ultr {
+constexpr long long kStaticWsFloats = 256 * 1024;  // 1 MiB per device
+static __device__ __align__(256) float scratch[kStaticWsFloats];
+constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mu;
+
+static int static_scratch(float** out) {
+  int dev = -1;
+  ULTR_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices, ULTR_EHIP,
+               "ultr_metrics_static: no current device (or ordinal above %d)", kMaxDevices - 1);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    ULTR_REQUIRE(e == hipSuccess && p, ULTR_EHIP, "ultr_metrics_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return ULTR_OK;
+}
+}  // namespace ultr
+
+extern "C" long long ultr_metrics_static_max_floats(void) { return kStaticWsFloats; }
+
+extern "C" int ultr_metrics_static(const float* scores, const float* labels, const int* docids, int n_rows,
+                                   const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
+                                   int n_topn, int metric_mask, float max_label, float* out, void* stream) {
+  ULTR_REQUIRE(B > 0 && n_topn >= 1 && ultr_metrics_workspace_floats(B, n_topn) <= kStaticWsFloats, ULTR_ELIMIT,
+               "ultr_metrics_static: B=%d lists with %d cutoffs need %lld workspace floats, the static array holds %lld "
+               "(use ultr_metrics with a workspace of your own)",
+               B, n_topn, ultr_metrics_workspace_floats(B > 0 ? B : 1, n_topn), kStaticWsFloats);
+  float* ws = nullptr;
+  int rc = static_scratch(&ws);
+  if (rc) return rc;
+  MetricsArgs a;
+  unsigned nblocks;
+  rc = prepare_metrics("ultr_metrics_static", scores, labels, docids, n_rows, list_weights, u_pred, B, Lx, topn_h, n_topn,
+                       metric_mask, max_label, out, ws, &a, &nblocks);
+  if (rc) return rc;
+  // the array keeps the last call's contents: the arrival counter (first 8 floats) must start at zero even if an
+  // earlier launch on this device was torn down half-way; the partial rows are overwritten before they are read
+  const hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), as_stream(stream));
+  ULTR_REQUIRE(e == hipSuccess, ULTR_EHIP, "ultr_metrics_static: hipMemsetAsync: %s", hipGetErrorString(e));
   return launch_metrics_now(a, nblocks, as_stream(stream));
 }
 
