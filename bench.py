@@ -74,8 +74,11 @@ def measured_traffic(kernel):
         if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
     if not files:
         return None
-    ent = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))['kernels'].get(kernel)
-    return ent['hbm_bytes'] if ent else None
+    kernels = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))['kernels']
+    for name, ent in kernels.items():  # template instances are listed as 'name<args>'
+        if name == kernel or name.startswith(kernel + '<'):
+            return ent['hbm_bytes']
+    return None
 
 
 def build_world(cfg, args, device):
@@ -117,8 +120,25 @@ def cpu_baseline(cfg, args, data, model):
     import random
     from oracle import torch_graph as TG
     from oracle import ultr_oracle as O
-    cores = min(os.cpu_count() or 1, 16)
+    # Threads: what this process may actually use -- OMP_NUM_THREADS when the environment sets it (the GPU box exports
+    # its CPU share that way: os.cpu_count() there is the whole machine's), else the affinity mask.  Nothing is capped
+    # silently: the source of the number, os.cpu_count() and the CPU model go into the output.
+    host_cpus = os.cpu_count() or 1
+    if os.environ.get('OMP_NUM_THREADS', '').isdigit():
+        cores, cores_from = int(os.environ['OMP_NUM_THREADS']), 'OMP_NUM_THREADS'
+    else:
+        cores, cores_from = len(os.sched_getaffinity(0)), 'sched_getaffinity'
+    cores = max(1, min(cores, host_cpus))
     torch.set_num_threads(cores)
+    cpu_model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                cpu_model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    log('  cpu_baseline: %s, os.cpu_count()=%d, torch threads=%d (from %s)' % (cpu_model, host_cpus, cores, cores_from))
     g = json.load(open(os.path.join(GOLDEN, cfg['click'])))
     kind = {'DLA': 'dla', 'IPWrank': 'ipw', 'RegressionEM': 'rem', 'PairDebias': 'pd'}[cfg['algo']]
     ps = model.model.unflatten(model.model.params)
@@ -156,15 +176,21 @@ def cpu_baseline(cfg, args, data, model):
         pw = None
         if kind == 'ipw':
             pw = [torch.tensor([O.propensity_for_one_list(ipw, clicks[b])[l] for b in range(B)]) for l in range(L)]
+        t_feed = time.time()
         ref.step(table, d, c, pw_lists=pw)
+        return t_feed
     one_step()  # warm-up
-    t0, n = time.time(), 0
+    t0, n, feed_s = time.time(), 0, 0.0
     while n < 3 or time.time() - t0 < args.cpu_seconds:
-        one_step()
+        t_in = time.time()
+        feed_s += one_step() - t_in
         n += 1
     dt = time.time() - t0
     return {'value': round(n * B / dt, 1), 'unit': 'query-lists/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d steps of batch %d (%.1f s): python feed loop + torch-CPU fp32 graph of the reference' % (n, B, dt)}
+            'cores_from': cores_from, 'host_cpus': host_cpus, 'cpu_model': cpu_model,
+            'feed_ms_per_step': round(1e3 * feed_s / n, 3), 'graph_ms_per_step': round(1e3 * (dt - feed_s) / n, 3),
+            'sample': '%d steps of batch %d (%.1f s): python feed loop (single-threaded, %.0f%% of the time) + torch-CPU '
+                      'fp32 graph of the reference on %d threads' % (n, B, dt, 100 * feed_s / dt, cores)}
 
 
 def main():
@@ -336,6 +362,11 @@ def main():
                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': measured_traffic(kname),
                         'launch_us': round(1e3 * ms, 3), 'flops_per_launch': fl}
+    step_gflop = train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9
+    if roofline:
+        # the whole step against the same peak: training flops of one step / measured step time / peak
+        roofline['step_frac'] = round(step_gflop / (1e3 * dt / args.steps) / PEAK_FP32_MFMA_TFLOPS, 4)  # GFLOP / ms = TFLOP/s
+        roofline['launches_per_step'] = round(sum(c for c, _ in kernels.values()) / float(nprof), 2)
 
     out = {
         'metric': 'train query-lists/sec (DNN+DLA, MSLR-10K shape)' if args.config == 'mslr10k'

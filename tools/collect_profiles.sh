@@ -3,10 +3,11 @@
 #   1. --kernel-trace --stats of the default bench command (per-kernel average durations)
 #   2. --pmc FETCH_SIZE   3. --pmc WRITE_SIZE   (separate passes; counters cannot share one)
 #   4. --pmc SQ MFMA / wait / LDS counters + GRBM_GUI_ACTIVE (MFMA utilisation of the scorer kernels)
-# Output under gpurun_out/prof_r01/; tools/make_traffic.py turns it into profiles/.
+# Output under gpurun_out/prof_<tag>/ (tag = $1, default r02); tools/make_traffic.py turns it into profiles/.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_r01
+TAG=${1:-r02}
+OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 100 --warmup 10 --no_cpu_baseline > $OUT/stats.log 2>&1

@@ -44,7 +44,7 @@ def newest(pattern):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
     src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
     dst = os.path.join(ROOT, 'profiles')
     os.makedirs(dst, exist_ok=True)
