@@ -99,6 +99,48 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     assert abs(got['local_loss'] - num / den) > 1e-9
 
 
+def _sync_worker(rank, world, port, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from ultra_amd.learning_algorithm.base_algorithm import BaseAlgorithm, HostVariable
+
+        class Replica(object):  # the attributes sync_replicas touches, on CPU tensors (the kernels need a GPU)
+            sync_replicas = BaseAlgorithm.sync_replicas
+            _replica_state = BaseAlgorithm._replica_state
+
+            def _extra_state(self):
+                return {'propensity': self.propensity}
+        r = Replica()
+        g = torch.Generator().manual_seed(100 + rank)  # replicas start APART (per-rank seeds)
+        r.world, r.rank, r.device = world, rank, torch.device('cpu')
+        r.model = SimpleNamespace(params=torch.randn(50, generator=g), _wt_state=('stale',))
+        r.acc = torch.rand(50, generator=g)
+        r.propensity = torch.rand(7, generator=g)
+        r.global_step = HostVariable(10 * (rank + 1))
+        r.sync_replicas()
+        assert r.model._wt_state is None and r._replicas_synced
+        state = (r.model.params.tolist(), r.acc.tolist(), r.propensity.tolist(), r.global_step.value)
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, state)
+        if rank == 0:
+            json.dump(gathered, open(out_path, 'w'))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_replicas_take_rank_zeros_variables(tmp_path):
+    out_path = str(tmp_path / 'sync.json')
+    mp.spawn(_sync_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    a, b = json.load(open(out_path))
+    assert a == b
+    g = torch.Generator().manual_seed(100)
+    assert a[0] == torch.randn(50, generator=g).tolist() and a[3] == 10
+
+
 def test_single_process_is_a_no_op():
     b = torch.arange(6, dtype=torch.float32)
     assert parallel.world_and_rank() == (1, 0)

@@ -58,9 +58,14 @@ class ClickSimulationFeed(BaseInputFeed):
             raise ValueError('rank_list_size %d > %d' % (self.rank_list_size, _lib.ULTR_MAX_LIST))
         self.world, self.rank = getattr(model, 'world', 1), getattr(model, 'rank', 0)
         self._upload_tables()
-        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
-        if hasattr(model, 'step_ctr'):
-            model.step_ctr = self.step_ctr  # regression-EM draws its Bernoulli uniforms on the same counter
+        # The device step counter keys the Philox draws of every assembled batch.  Regression-EM keys its Bernoulli
+        # labels on the same counter, so a model that has one shares it with ALL its feeds: the first feed creates it,
+        # later feeds (a second training feed, a feed built for validation) advance the same counter instead of
+        # replacing it -- a replaced counter would leave the model reading one that no batch advances any more.
+        shared = getattr(model, 'step_ctr', None)
+        self.step_ctr = shared if shared is not None else torch.zeros(1, dtype=torch.int32, device=self.device)
+        if hasattr(model, 'step_ctr') and shared is None:
+            model.step_ctr = self.step_ctr
         self.info = torch.zeros(36, dtype=torch.int32, device=self.device)
         self._out = {}
         # prefetch: (data set, batch size, check_validation) the buffers were last filled / parked for

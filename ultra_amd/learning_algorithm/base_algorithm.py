@@ -320,8 +320,34 @@ class BaseAlgorithm(ABC):
 
     # The three phases of a training step, callable one by one so that a data-parallel driver can replay the two
     # compute phases as hipGraphs and issue the collective between them (bench.py does; RCCL stays outside capture).
+    def sync_replicas(self, src=0):
+        """Data parallel: every replica takes rank ``src``'s variables -- ranker parameters, optimiser accumulators,
+        the algorithm's own state (propensity tower, EM state) and the step count.  The step itself needs no broadcast
+        (every rank applies the same all-reduced bucket to the same variables), but that argument starts from equal
+        variables: equal seeds give them, a per-rank seed or a checkpoint restored on one rank only does not.  Runs
+        once before the first training step and after load_state_dict; no-op without a process group."""
+        self._replicas_synced = True
+        if self.world <= 1 or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return
+        tensors = [self.model.params]
+        if getattr(self, 'acc', None) is not None:
+            tensors.append(self.acc)
+        tensors += [v for _, v in sorted(self._replica_state().items())]
+        for t in tensors:
+            torch.distributed.broadcast(t, src=src)
+        gs = torch.tensor([self.global_step.value], dtype=torch.int64, device=self.device)
+        torch.distributed.broadcast(gs, src=src)
+        self.global_step.value = int(gs.item())
+        self.model._wt_state = None  # the fused step's transposed weight copies follow the new parameters
+
+    def _replica_state(self):
+        """Device tensors beside params / acc that must be equal on every replica (default: the checkpointed extras)."""
+        return self._extra_state()
+
     def step_local(self, input_feed):
         """Everything before the collective: scores, loss + d_scores, in-step metrics, flat un-normalised gradient."""
+        if self.world > 1 and not getattr(self, '_replicas_synced', False):
+            self.sync_replicas()
         L = self.rank_list_size
         batch = self._to_device_batch(input_feed, L)
         tb = self._train_buffers(batch.B)
@@ -522,6 +548,7 @@ class BaseAlgorithm(ABC):
         for k, v in self._extra_state().items():
             if k in sd:
                 v.copy_(sd[k])
+        self._replicas_synced = False  # a restore on some ranks only must not leave the replicas apart
 
     def _extra_state(self):
         return {}

@@ -33,6 +33,7 @@ class IPWrank(BaseAlgorithm):
             L = self.rank_list_size
             self.ipw_table = torch.tensor(self.propensity_estimator.ipw_table(L), dtype=torch.float32,
                                           device=self.device)
+            self._ipw_host = self.ipw_table.cpu().numpy()
             self._pw = None
 
     def step(self, session, input_feed, forward_only):
@@ -76,7 +77,13 @@ class IPWrank(BaseAlgorithm):
     def _summary(self, stats, local, n_lists):
         out = {}
         for i in range(self.rank_list_size):
-            out['Propensity weights %d' % i] = stats[2 + i] / self.world  # reduce_max (ipw_rank.py:120-125)
+            # reduce_max over the batch (ipw_rank.py:120-125).  A maximum is not additive, but the weights are
+            # (propensity_estimator.py:33-42) IPW[l] where clicked and 0 elsewhere: the summed per-rank maxima are
+            # positive exactly when some rank saw a click at l, and then the global maximum is the table entry.
+            if self.world > 1:
+                out['Propensity weights %d' % i] = self._ipw_host[i] if stats[2 + i] > 0 else 0.0
+            else:
+                out['Propensity weights %d' % i] = stats[2 + i]
         out['Learning Rate'] = self.learning_rate.value
         out['Loss'] = self._loss_value(stats, local)
         return out
