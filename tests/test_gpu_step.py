@@ -520,3 +520,40 @@ def test_hipgraph_replay_equals_eager_steps(algo):
     for p1, a1, e1, l1 in results[1:]:
         assert torch.equal(p0, p1) and torch.equal(a0, a1) and torch.equal(e0, e1)
         assert l0 == l1 and np.isfinite(l0)
+
+
+def test_rem_draws_fresh_bernoulli_labels_every_step_without_the_device_sampler():
+    """device_rng=False: no kernel advances a device step counter, so regression-EM must key its Bernoulli labels
+    (regression_EM.py:29-39,158: fresh tf.random_uniform per session.run) on its own step count.  Frozen variables
+    (learning rate 0, EM step 0) and the same batch twice: d_scores = sigmoid(score + b) - label differ iff the draws do."""
+    data = SyntheticData(80, 10, 24, seed=2)
+    exp = settings('RegressionEM', 'learning_rate=0.0,EM_step_size=0.0',
+                   feed_hparams='click_model_json=%s,device_rng=false' % PBM)
+    m, feed = make('RegressionEM', data, exp, 32)
+    assert m.step_ctr is None
+    random.seed(5)
+    fd, _ = feed.get_batch(data, check_validation=True)
+    m.step(None, fd, False)
+    d0 = m._train_bufs['d_scores'].clone()
+    m.step(None, fd, False)
+    d1 = m._train_bufs['d_scores'].clone()
+    assert not torch.equal(d0, d1)
+    # with the device sampler the feed's counter is the key, shared by every feed built on the model
+    m2, feed2 = make('RegressionEM', data, settings('RegressionEM'), 32)
+    assert m2.step_ctr is feed2.step_ctr
+
+
+def test_a_step_result_read_after_its_slot_was_reused_raises():
+    data = SyntheticData(80, 10, 24, seed=2)
+    m, feed = make('DLA', data, settings('DLA'), 16)
+    fd, _ = feed.get_batch(data, check_validation=True)
+    first_loss, _, _ = m.step(None, fd, False)
+    _, _, second_summary = m.step(None, fd, False)
+    for _ in range(62):
+        loss, _, _ = m.step(None, fd, False)
+    assert np.isfinite(float(first_loss))          # 63 steps later: still its own row
+    m.step(None, fd, False)
+    m.step(None, fd, False)                        # the second step's slot has been handed out again
+    with pytest.raises(RuntimeError, match='more than 64 steps'):
+        second_summary.as_dict()
+    assert np.isfinite(float(loss))

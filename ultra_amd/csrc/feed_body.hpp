@@ -73,8 +73,8 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
   __syncthreads();
   // A hipGraph replays frozen kernel arguments, so the per-step Philox counter lives in device memory.  One thread
   // per block reads it and hands it to the others through LDS; the bump needs no hand-off of data, only "every block
-  // has read the counter": the block arrives right after its read (the increment is made to depend on the value
-  // read, so it cannot overtake the read) and the last arriver bumps -- at the START of the kernel, off the critical
+  // has read the counter": the block arrives right after its read has RETURNED (s_waitcnt between the two, so the
+  // arrival cannot overtake the read) and the last arriver bumps -- at the START of the kernel, off the critical
   // path, with no release/acquire fence.
   if (step_ctr) {
     __shared__ unsigned int s_cur;
@@ -84,7 +84,10 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
       // two levels (16 sub-counters, then info[3]): a thousand returning atomics on one address take 16 us
       unsigned int* sub = reinterpret_cast<unsigned int*>(&info[20 + (bid & 15)]);
       const unsigned int n_sub = ((unsigned)nb - (unsigned)(bid & 15) + 15u) / 16u;  // blocks that share this sub-counter
-      const unsigned int t = __hip_atomic_fetch_add(sub, 1u + (cur & 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the arrival must not be issued before the counter value has come back: wait for the load, and keep the
+      // compiler from moving either memory operation across this point
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int t = __hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t == n_sub - 1) {
         __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned int* arrive = reinterpret_cast<unsigned int*>(&info[3]);

@@ -62,9 +62,11 @@ class ClickSimulationFeed(BaseInputFeed):
         # labels on the same counter, so a model that has one shares it with ALL its feeds: the first feed creates it,
         # later feeds (a second training feed, a feed built for validation) advance the same counter instead of
         # replacing it -- a replaced counter would leave the model reading one that no batch advances any more.
+        # Only a feed that advances the counter hands it over (the device sampler, mode 0): with device_rng=False no
+        # kernel ever bumps it, and the model must key its draws on its own step count instead.
         shared = getattr(model, 'step_ctr', None)
         self.step_ctr = shared if shared is not None else torch.zeros(1, dtype=torch.int32, device=self.device)
-        if hasattr(model, 'step_ctr') and shared is None:
+        if hasattr(model, 'step_ctr') and shared is None and self.hparams.device_rng:
             model.step_ctr = self.step_ctr
         self.info = torch.zeros(36, dtype=torch.int32, device=self.device)
         self._out = {}

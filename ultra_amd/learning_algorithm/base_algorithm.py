@@ -229,6 +229,7 @@ class BaseAlgorithm(ABC):
         n_host = self.n_stats + n_met + self.N_LOCAL
         tb['host'] = torch.zeros((64, n_host), dtype=torch.float32).pin_memory()
         tb['events'] = [None] * 64
+        tb['gen'] = [0] * 64     # how often each slot has been handed out: a late reader notices a recycled slot
         tb['slot'] = 0
         tb['fixed_slot'] = getattr(self, '_fixed_slot_default', False)
         self._train_bufs = tb
@@ -299,9 +300,17 @@ class BaseAlgorithm(ABC):
         if not capturing:
             ev = torch.cuda.Event()
             ev.record()
-        stamp = tb['slot']
+        tb['gen'][slot] += 1
+        stamp = tb['gen'][slot]
+        ring = not tb['fixed_slot']
 
         def fetch():
+            # Results are read lazily from a ring of 64 pinned rows: reading one more than 64 steps after its step
+            # would silently return a later step's row.  (Under hipGraph replay every step lands in ONE slot by
+            # design -- replays are invisible to the host -- and a result means "the latest replay".)
+            if ring and tb['gen'][slot] != stamp:
+                raise RuntimeError('this step result was first read more than 64 steps after its step: its pinned '
+                                   'slot has been reused (read losses / summaries within 64 steps)')
             if ev is not None:
                 ev.synchronize()
             else:
