@@ -12,9 +12,37 @@
  *   - all pointers are DEVICE pointers unless the name ends in _h (host);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - return 0 on success, negative ULTR_E* on error; ultr_last_error() gives the text;
- *   - no entry point allocates or frees device memory, synchronises, or keeps state between
- *     calls other than what the caller passes in (workspaces), so calls are capturable in a
- *     hipGraph and re-entrant per stream (two calls sharing one workspace must be ordered);
+ *   - no entry point allocates or frees device memory or synchronises, so calls are capturable
+ *     in a hipGraph; two calls sharing one workspace must be ordered;
+ *   - state between calls.  The plain entry points keep none beyond what the caller passes in
+ *     (workspaces) and are re-entrant per stream.  Three families do keep state, all of it on the
+ *     host side of the library:
+ *       (1) the *_deferred calls (ultr_loss_*_deferred, ultr_metrics_deferred,
+ *           ultr_batch_assemble_deferred) PARK one request per kind PER HOST THREAD (thread_local):
+ *           nothing is launched; a later carrying call made BY THE SAME THREAD (ultr_dnn_backward*,
+ *           ultr_dnn_train_fused, ultr_clip_adagrad_fused; each request's comment names its carriers)
+ *           launches the parked work inside one of its own launches, on the CARRIER's stream.
+ *           What follows from that:
+ *           - every pointer of a parked request must stay valid until it has been carried, flushed
+ *             (ultr_*_flush launches it on its own) or cancelled (ultr_*_cancel drops it);
+ *           - parking a second request of a kind launches the first one on its own, at once;
+ *           - a loss request is only differentiated in place by a carrier whose d_scores / scores
+ *             buffer and B*L are the request's own; any other carrier launches it on its own first
+ *             (ultr_dnn_train_fused refuses instead).  Metric and assembly requests do not depend on
+ *             the carrier's data and ride with whichever carrier of that thread comes next -- so with
+ *             two models stepped alternately on one thread each request still runs exactly once,
+ *             before or inside the next carrier, but an ASSEMBLY parked for model A is flushed early
+ *             (into A's live batch buffers) if model B parks its own before A has stepped: step the
+ *             models one whole step at a time, or do not prefetch;
+ *           - a carrier called from ANOTHER thread does not see the request (flush it), and a
+ *             carrier on another stream runs it on that stream, unordered against the stream the
+ *             request's inputs were produced on;
+ *           - the non-deferred twins of every call (ultr_loss_*_fwdbwd, ultr_metrics,
+ *             ultr_batch_assemble) keep no state;
+ *       (2) ultr_profile_* (process-wide event lists, off by default);
+ *       (3) ultr_metrics_static (a per-device scratch array inside the library);
+ *     and a handful of launch-plan experiment switches (ULTR_* environment variables)
+ *     are read once per process, at first use;
  *   - "position-major" [L][B]: element (list b, rank l) is at l*B + b, i.e. the row order of
  *     DNN.build's axis-0 concat (DNN.py:65);
  *   - a doc id equal to n_rows denotes the zero pad row (base_algorithm.py:120-123).

@@ -1708,7 +1708,7 @@ static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st, const c
     return WK == 1 ? launch_fwd<4, 1, true>(a, st, name) : launch_fwd<4, 2, true>(a, st, name);
   }
   const long long base = tilesM * tilesN;
-  const char* v = getenv("ULTR_FWD_VARIANT");  // experiment switch: "41", "22", "14", "42", "81"
+  static const char* const v = getenv("ULTR_FWD_VARIANT");  // experiment switch, read once: "41", "22", "14", "42", "81"
   if (v) {
     if (!strcmp(v, "41")) return launch_fwd<4, 1, false>(a, st, name);
     if (!strcmp(v, "22")) return launch_fwd<2, 2, false>(a, st, name);
@@ -2036,7 +2036,8 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   int carrier = -1;
   if (g_pending_metrics.on) {
     if (H >= 1 && g_pending_metrics.nblocks <= 64) carrier = 0;  // a bigger request is no rider: a launch of its own
-    if (const char* e = getenv("ULTR_RIDE_CARRIER")) carrier = atoi(e) < H && !pair_mask ? atoi(e) : carrier;  // experiments
+    static const int carrier_env = [] { const char* e = getenv("ULTR_RIDE_CARRIER"); return e ? atoi(e) : -1; }();  // experiments
+    if (carrier_env >= 0 && carrier_env < H && !pair_mask) carrier = carrier_env;
     if (carrier < 0) {
       g_pending_metrics.on = false;
       rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, st);

@@ -73,10 +73,24 @@ class ClickSimulationFeed(BaseInputFeed):
         # prefetch: (data set, batch size, check_validation) the buffers were last filled / parked for
         self._prefetched = None
 
+    # The library parks ONE assembly request per host thread (include/ultr_hip.h, Conventions); several feeds may live
+    # on a thread, so the feeds remember whose request was parked last: a feed drops only its own request, and launches
+    # (never drops) one that may belong to another feed.
+    _parked_owner = None  # id() of the feed that parked last
+
+    def _drop_parked(self):
+        lib = _lib.lib()
+        if ClickSimulationFeed._parked_owner == id(self):
+            lib.ultr_batch_assemble_cancel()
+        else:  # another feed's next batch (or nothing at all): it runs now, on its own
+            _lib.check(lib.ultr_batch_assemble_flush(_lib.current_stream()), 'ultr_batch_assemble_flush')
+        ClickSimulationFeed._parked_owner = None
+
     def __del__(self):
         try:
-            if self._prefetched is not None:
+            if self._prefetched is not None and ClickSimulationFeed._parked_owner == id(self):
                 _lib.lib().ultr_batch_assemble_cancel()  # the parked request points into buffers that go away with us
+                ClickSimulationFeed._parked_owner = None
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
@@ -170,9 +184,10 @@ class ClickSimulationFeed(BaseInputFeed):
             # per-position feed entries) must therefore be read before the step that follows this call.
             key = (id(dd), B, bool(check_validation))
             if self._prefetched != key:
-                _lib.lib().ultr_batch_assemble_cancel()  # a request parked for other arguments is dropped
+                self._drop_parked()  # a request this feed parked for other arguments is dropped
                 self._assemble(dd, o, B, 0, check_validation=check_validation)
             self._assemble_deferred(dd, o, B, check_validation)
+            ClickSimulationFeed._parked_owner = id(self)
             self._prefetched = key
         elif self.hparams.device_rng:
             self._assemble(dd, o, B, 0, check_validation=check_validation)
