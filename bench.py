@@ -44,6 +44,7 @@ CONFIGS = {
 }
 HIDDEN = [512, 256, 128]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (16 x the fp32 matrix rate)
 
 
 def log(*a):
@@ -99,7 +100,8 @@ def build_world(cfg, args, device):
     else:
         data = SyntheticData(cfg['Q'], cfg['L'], cfg['F'], seed=1234, pad_frac=0.1)
     exp = {'ranking_model': 'ultra_amd.ranking_model.DNN',
-           'ranking_model_hparams': 'hidden_layer_sizes=[512, 256, 128]',
+           'ranking_model_hparams': 'hidden_layer_sizes=[512, 256, 128],compute_dtype=%s' % (
+               'bf16' if args.dtype == 'bf16' else 'f32'),
            'learning_algorithm': 'ultra_amd.learning_algorithm.' + cfg['algo'],
            'learning_algorithm_hparams': args.algo_hparams,
            'metrics': ['mrr', 'ndcg'], 'metrics_topn': [3, 5, 10],
@@ -210,6 +212,10 @@ def main():
     ap.add_argument('--prefetch', type=int, default=1,
                     help='feed hparam prefetch: batch t+1 is assembled inside the last launch of step t (every step still '
                          'assembles exactly one batch)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='f32: the parity path (headline).  bf16: the opt-in fast path -- forward and dgrad GEMMs of the '
+                         'hidden layers on bf16 MFMA with fp32 accumulation, the rest fp32 (bound: DESIGN.md section 3); '
+                         'its roofline is priced against the bf16 matrix peak')
     ap.add_argument('--cpu_seconds', type=float, default=12.0)
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')
@@ -358,13 +364,15 @@ def main():
             name, fl, ms = best
             achieved = fl / (ms * 1e-3) / 1e12
             kname = name.split('/')[0]
+            peak = PEAK_BF16_MFMA_TFLOPS if kname.endswith('_bf16') else PEAK_FP32_MFMA_TFLOPS
             roofline = {'kernel': kname, 'gemm': name.split('/')[1] + (' (sum of K N over the hidden layers)' if '/P' in name else ''), 'bound': 'mfma', 'achieved': round(achieved, 3),
-                        'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': measured_traffic(kname),
+                        'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / peak, 4), 'traffic': measured_traffic(kname),
                         'launch_us': round(1e3 * ms, 3), 'flops_per_launch': fl}
     step_gflop = train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9
     if roofline:
         # the whole step against the same peak: training flops of one step / measured step time / peak
+        # (always against the fp32 matrix peak: the weight gradients -- a third of the flops -- run fp32 MFMA in both modes)
         roofline['step_frac'] = round(step_gflop / (1e3 * dt / args.steps) / PEAK_FP32_MFMA_TFLOPS, 4)  # GFLOP / ms = TFLOP/s
         roofline['launches_per_step'] = round(sum(c for c, _ in kernels.values()) / float(nprof), 2)
 
@@ -373,7 +381,7 @@ def main():
         else 'train query-lists/sec (%s)' % args.config,
         'value': round(value, 1), 'unit': 'query-lists/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 5), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not cfg.get('data_dir') else 'toy libsvm data of the reference (example/toy/data)',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic' if not cfg.get('data_dir') else 'toy libsvm data of the reference (example/toy/data)',
         'config': {'workload': '%s shape: %d features, list %d, batch %d lists/GPU, DNN[512,256,128] + %s, %s clicks, '
                                '%d %s queries resident in HBM' % (
                                    args.config, cfg['F'], cfg['L'], args.batch, cfg['algo'],

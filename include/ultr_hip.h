@@ -81,6 +81,12 @@ enum { ULTR_LOSS_SOFTMAX = 0, ULTR_LOSS_SIGMOID = 1 };
 enum { ULTR_PROB_SOFTMAX = 0, ULTR_PROB_SIGMOID = 1 };
 /* grad_strategy hparam (dla.py:183-185) */
 enum { ULTR_OPT_ADAGRAD = 0, ULTR_OPT_SGD = 1 };
+/* compute_dtype hparam of the scorer (new; DNN.py:85-93 is the matmul it applies to).  F32: fp32 MFMA, the parity path.
+ * BF16: opt-in fast path -- the forward and dgrad GEMMs of the hidden layers multiply bf16-rounded operands (activations
+ * rounded on the fly, weights from packed bf16 copies that the update launch keeps current) and accumulate in fp32;
+ * LayerNorm, activations, losses, the output layer, the weight gradients' accumulation and the optimiser stay fp32, and
+ * the parameters are fp32 master copies.  Stated error bound: DESIGN.md section 3. */
+enum { ULTR_DTYPE_F32 = 0, ULTR_DTYPE_BF16 = 1 };
 /* metric bits for ultr_metrics */
 enum { ULTR_METRIC_MRR = 1, ULTR_METRIC_NDCG = 2, ULTR_METRIC_ERR = 4 };
 
@@ -99,6 +105,8 @@ typedef struct UltrDnnDesc {
   long long off_gamma[ULTR_MAX_LAYERS];
   long long off_beta[ULTR_MAX_LAYERS];
   long long n_params;           /* length of the flat buffer (padding included)      */
+  int compute_dtype;            /* ULTR_DTYPE_*: arithmetic of the hidden layers' GEMMs in the fused training step
+                                 * (ultr_dnn_train_fused); every other entry point computes in fp32 whatever it says */
 } UltrDnnDesc;
 
 int ultr_version(void);

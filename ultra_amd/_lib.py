@@ -15,6 +15,7 @@ ULTR_MAX_LIST = 64
 
 ACT = {'elu': 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid': 4}
 NORM_NONE, NORM_LAYER = 0, 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
 CLICK_PBM, CLICK_CASCADE, CLICK_ORACLE, CLICK_TABLE, CLICK_UBM = 0, 1, 2, 3, 4
 LOSS_SOFTMAX, LOSS_SIGMOID = 0, 1
 PROB_SOFTMAX, PROB_SIGMOID = 0, 1
@@ -40,6 +41,7 @@ class UltrDnnDesc(ctypes.Structure):
         ('off_gamma', ctypes.c_longlong * ULTR_MAX_LAYERS),
         ('off_beta', ctypes.c_longlong * ULTR_MAX_LAYERS),
         ('n_params', ctypes.c_longlong),
+        ('compute_dtype', ctypes.c_int),
     ]
 
 

@@ -1737,6 +1737,8 @@ int ultr_check_desc(const UltrDnnDesc* d, const char* who) {
                who, d->activation);
   ULTR_REQUIRE(d->norm == ULTR_NORM_NONE || d->norm == ULTR_NORM_LAYER, ULTR_EINVAL,
                "%s: norm=%d (batch normalisation is not on the device path)", who, d->norm);
+  ULTR_REQUIRE(d->compute_dtype == ULTR_DTYPE_F32 || d->compute_dtype == ULTR_DTYPE_BF16, ULTR_EINVAL,
+               "%s: compute_dtype=%d", who, d->compute_dtype);
   for (int j = 0; j < d->n_layers; ++j)
     ULTR_REQUIRE((d->off_W[j] & 3) == 0 && (d->off_b[j] & 3) == 0 && (d->off_gamma[j] & 3) == 0 &&
                      (d->off_beta[j] & 3) == 0,

@@ -51,6 +51,8 @@ struct TcArgs {
   int has_ln; float eps; int activation; int H;
   int B, L, nl;                                   // nl lists of L ranks per workgroup, nl * L <= 16
   const float* W[ULTR_MAX_LAYERS]; const float* WT[ULTR_MAX_LAYERS];
+  // bf16 instantiations stream these instead: W_j resp. W_j^T packed [rows / 4][ld][4] bf16 (pack_weights_kernel)
+  const float* Wp[ULTR_MAX_LAYERS]; const float* WTp[ULTR_MAX_LAYERS];
   const float* bias[ULTR_MAX_LAYERS]; const float* gamma[ULTR_MAX_LAYERS]; const float* beta[ULTR_MAX_LAYERS];
   int K[ULTR_MAX_LAYERS], N[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS];
   float* xhat[ULTR_MAX_LAYERS];                   // [M][round4(K_j)]  normalised input rows of layer j, list-major rows
@@ -96,8 +98,29 @@ __device__ __forceinline__ TcGeo tc_geo(const float* W, int K, int N, int ld, in
 // FAST: the contraction length may stop short of the last chunk's 16 rows (layer 0 only: hidden widths are multiples
 // of 16); those rows are read all the same -- they lie inside the parameter buffer (checked on the host), are finite,
 // and meet zeros in the panel -- so the loop carries no clamps and no tail path.
-template <bool FAST>
+// BF: the matrix is the packed bf16 copy -- element (k, n) at ((k / 4) * ld + n) * 4 + k % 4 (in bf16), rows padded with
+// zeros to a multiple of 16 -- so a lane's 4 x 4 block of chunk i (rows 16 c + 4 kk .. + 3, columns colc .. colc + 3) is
+// 32 contiguous bytes, half of what the fp32 stream moves, and the last chunk needs neither clamps nor over-reads.
+typedef short tc_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tc_s16x4 tc_bf16x4(float a, float b, float c, float d) {
+  const uint2 u = make_uint2(pk_bf16(a, b), pk_bf16(c, d));
+  return __builtin_bit_cast(tc_s16x4, u);
+}
+__device__ __forceinline__ tc_s16x4 tc_as_bf16x4(float lo, float hi) {
+  const float2 u = make_float2(lo, hi);
+  return __builtin_bit_cast(tc_s16x4, u);
+}
+template <bool FAST, bool BF>
 __device__ __forceinline__ void tc_wload(const TcGeo& g, int colc, unsigned voff, int i, int kk, TcFrag& S) {
+  if (BF) {
+    const bool on = i < g.nch;  // wave-uniform; past the end every lane re-reads the head of the stream (see below)
+    const int c = on ? g.c_begin + i : 0;
+    const float* rowp = g.W + (size_t)(8 * c) * g.ld;  // 4 c quad-rows of ld * 8 bytes
+    const unsigned vo = on ? voff : 0u;
+    S.b[0] = *reinterpret_cast<const float4*>(rowp + vo);
+    S.b[1] = *reinterpret_cast<const float4*>(rowp + vo + 4);
+    return;
+  }
 #ifdef ULTR_STAMPS
   if (g.dbg & 1) {
 #pragma unroll
@@ -123,14 +146,18 @@ __device__ __forceinline__ void tc_wload(const TcGeo& g, int colc, unsigned voff
       S.b[s] = *reinterpret_cast<const float4*>(g.W + (size_t)min(k0 + s, g.K - 1) * g.ld + colc);
   }
 }
-template <bool FAST>
+// per-lane offset (in floats) of the lane's block inside a chunk
+template <bool BF> __device__ __forceinline__ unsigned tc_voff(const TcGeo& g, int colc, int kk) {
+  return BF ? (unsigned)(2 * (kk * g.ld + colc)) : (unsigned)(4 * kk * g.ld + colc);
+}
+template <bool FAST, bool BF>
 __device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcFrag& S0, TcFrag& S1, TcFrag& S2) {
   if (g.u_first < g.U) {
     const int colc = min(64 * g.u_first + 4 * nn, g.ld - 4);
-    const unsigned voff = (unsigned)(4 * kk * g.ld + colc);
-    tc_wload<FAST>(g, colc, voff, 0, kk, S0);
-    tc_wload<FAST>(g, colc, voff, 1, kk, S1);
-    tc_wload<FAST>(g, colc, voff, 2, kk, S2);
+    const unsigned voff = tc_voff<BF>(g, colc, kk);
+    tc_wload<FAST, BF>(g, colc, voff, 0, kk, S0);
+    tc_wload<FAST, BF>(g, colc, voff, 1, kk, S1);
+    tc_wload<FAST, BF>(g, colc, voff, 2, kk, S2);
   }
 }
 
@@ -154,7 +181,7 @@ __device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcFr
 // multiplied out it serves as the split-K exchange buffer.  epi(u, acc) receives the finished unit:
 // acc[t][r] = out[row 4 kk + r][col 64 u + 4 nn + t].  The first three weight chunks of the wave's first unit must
 // already be in S0 / S1 / S2 (tc_prefetch).
-template <bool FAST, class Epi>
+template <bool FAST, bool BF, class Epi>
 __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn, int kk, int lane, TcFrag& S0,
                                         TcFrag& S1, TcFrag& S2, TcFrag& S3, Epi epi, int stamp = -1) {
   if (stamp >= 0) TC_STAMP(stamp);
@@ -164,16 +191,25 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int colc = min(64 * u + 4 * nn, g.ld - 4);
-    const unsigned voff = (unsigned)(4 * kk * g.ld + colc);
+    const unsigned voff = tc_voff<BF>(g, colc, kk);
     if (u != g.u_first) {
-      tc_wload<FAST>(g, colc, voff, 0, kk, S0);
-      tc_wload<FAST>(g, colc, voff, 1, kk, S1);
-      tc_wload<FAST>(g, colc, voff, 2, kk, S2);
+      tc_wload<FAST, BF>(g, colc, voff, 0, kk, S0);
+      tc_wload<FAST, BF>(g, colc, voff, 1, kk, S1);
+      tc_wload<FAST, BF>(g, colc, voff, 2, kk, S2);
     }
     float4 a_cur = *reinterpret_cast<const float4*>(arow);
     auto compute = [&](TcFrag& S, int i) {
       // the panel values of the NEXT chunk are requested before this chunk's MFMAs: their LDS latency runs under them
       const float4 a_nxt = *reinterpret_cast<const float4*>(arow + 16 * min(i + 1, g.nch - 1));
+      if (BF) {  // one bf16 MFMA (16 x 16 x 16, fp32 accumulate) per column group takes the place of four fp32 ones
+        const tc_s16x4 av = tc_bf16x4(a_cur.x, a_cur.y, a_cur.z, a_cur.w);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, tc_as_bf16x4(S.b[0].x, S.b[0].y), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, tc_as_bf16x4(S.b[0].z, S.b[0].w), acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, tc_as_bf16x4(S.b[1].x, S.b[1].y), acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, tc_as_bf16x4(S.b[1].z, S.b[1].w), acc[3], 0, 0, 0);
+        a_cur = a_nxt;
+        return;
+      }
       const float a[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -184,7 +220,7 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
       }
       a_cur = a_nxt;
     };
-#define TC_LOAD(i, S) tc_wload<FAST>(g, colc, voff, (i), kk, S)
+#define TC_LOAD(i, S) tc_wload<FAST, BF>(g, colc, voff, (i), kk, S)
 #define TC_COMPUTE(S, i) compute(S, (i))
     TC_STREAM4(g.nch, TC_LOAD, TC_COMPUTE);
 #undef TC_LOAD
@@ -242,7 +278,9 @@ template <bool FAST> __device__ __forceinline__ bool tc_ok(int k, int e, int K) 
 __device__ __forceinline__ void tc_unpack(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 
 // NQ: float4 per lane and row the stages are compiled for (256 NQ >= the widest layer input, rounded up to 16)
-template <int RIDE, bool FAST, int NQ>
+// BF: the hidden layers' GEMMs (forward and dgrad) multiply bf16-rounded activations with the packed bf16 weight copies,
+// accumulating in fp32; everything between the GEMMs (LayerNorm, activations, loss, the output layer) stays fp32.
+template <int RIDE, bool FAST, int NQ, bool BF>
 __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -273,9 +311,9 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     rm[r2] = rvalid[r2] ? b * L + l : 0;
   }
   // ---- layer 0: weights first, then the rows (doc id -> table row + statistics: two dependent round trips)
-  TcGeo g = tc_geo(p.W[0], p.K[0], p.N[0], p.ldn[0], w);
+  TcGeo g = tc_geo(BF ? p.Wp[0] : p.W[0], p.K[0], p.N[0], p.ldn[0], w);
   g.dbg = p.dbg;
-  tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
+  tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
   int docid[2];
 #pragma unroll
   for (int r2 = 0; r2 < 2; ++r2) docid[r2] = rvalid[r2] ? p.docids[re[r2]] : p.n_rows;
@@ -325,11 +363,16 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   {
     const int xi = blockIdx.x >> 3, nx = (gridDim.x + 7) >> 3;
     for (int j = 0; j < H; ++j) {
-      const long long tot = (long long)p.K[j] * p.ldn[j], totT = j >= 1 ? (long long)p.N[j] * ((p.K[j] + 3) & ~3) : 0;
+      // floats of the streamed copy: the fp32 matrix, or half as many for the packed bf16 one (rows padded to 16)
+      const long long tot = BF ? (long long)((p.K[j] + 15) & ~15) * p.ldn[j] / 2 : (long long)p.K[j] * p.ldn[j];
+      const long long totT = j < 1 ? 0 : BF ? (long long)((p.N[j] + 15) & ~15) * ((p.K[j] + 3) & ~3) / 2
+                                            : (long long)p.N[j] * ((p.K[j] + 3) & ~3);
       const long long lines = (tot + 31) >> 5, linesT = (totT + 31) >> 5;
       const long long per = (lines + nx - 1) / nx, perT = (linesT + nx - 1) / nx;
-      for (long long i = xi * per + tid; i < min((xi + 1) * per, lines); i += kTcThreads) warm += p.W[j][i * 32];
-      for (long long i = xi * perT + tid; i < min((xi + 1) * perT, linesT); i += kTcThreads) warm += p.WT[j][i * 32];
+      const float* wj = BF ? p.Wp[j] : p.W[j];
+      const float* wtj = BF ? p.WTp[j] : p.WT[j];
+      for (long long i = xi * per + tid; i < min((xi + 1) * per, lines); i += kTcThreads) warm += wj[i * 32];
+      for (long long i = xi * perT + tid; i < min((xi + 1) * perT, linesT); i += kTcThreads) warm += wtj[i * 32];
     }
   }
 
@@ -408,7 +451,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     float* actj = smem + p.act_off[j];
     const int aps = p.act_ps[j];
     const float* biasj = p.bias[j];
-    tc_gemm<FAST>(g, P1, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
+    tc_gemm<FAST, BF>(g, P1, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
       const int col0 = 64 * u + 4 * nn;
       const int n16 = (N + 15) & ~15;
       const float4 b4 = *reinterpret_cast<const float4*>(biasj + min(col0, ((N + 3) & ~3) - 4));
@@ -426,9 +469,9 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     }, j == 2 ? 10 : -1);
     TC_STAMP(2 + 3 * j);
     if (j + 1 < H) {  // the next layer's weight stream starts before its rows are normalised
-      g = tc_geo(p.W[j + 1], p.K[j + 1], p.N[j + 1], p.ldn[j + 1], w);
+      g = tc_geo(BF ? p.Wp[j + 1] : p.W[j + 1], p.K[j + 1], p.N[j + 1], p.ldn[j + 1], w);
       g.dbg = p.dbg;
-      tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
+      tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
     }
     lds_barrier();  // the layer's activations are complete
     TC_STAMP(3 + 3 * j);
@@ -672,9 +715,9 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   // the transposed weights of the first dgrad GEMM stream in under the partial-row reduction
   int cur_is_p1 = 1;
   if (H >= 2) {
-    g = tc_geo(p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w);
+    g = tc_geo(BF ? p.WTp[H - 1] : p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w);
     g.dbg = p.dbg;
-    tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
+    tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
   }
   TC_STAMP(17);
   lds_barrier();
@@ -708,7 +751,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memtime();
 #endif
     if (j == 1) TC_WSTAMP(0);
-    tc_gemm<FAST>(g, cur, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
+    tc_gemm<FAST, BF>(g, cur, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
       const int col0 = 64 * u + 4 * nn;
       if (col0 < K16) {
 #pragma unroll
@@ -717,9 +760,9 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
       }
     });
     if (j >= 2) {  // the next layer's weight stream starts under the row pass
-      g = tc_geo(p.WT[j - 1], p.N[j - 1], p.K[j - 1], (p.K[j - 1] + 3) & ~3, w);
+      g = tc_geo(BF ? p.WTp[j - 1] : p.WT[j - 1], p.N[j - 1], p.K[j - 1], (p.K[j - 1] + 3) & ~3, w);
       g.dbg = p.dbg;
-      tc_prefetch<FAST>(g, nn, kk, S0, S1, S2);
+      tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
     }
 #ifdef ULTR_STAMPS
     if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memtime();
@@ -811,6 +854,26 @@ __global__ void __launch_bounds__(256) transpose_weights_kernel(TransposeArgs p)
   __syncthreads();
   for (int r = r0; r < 32; r += 8)
     if (n0 + r < N && k0 + c < ldk) p.WT[j][(long long)(n0 + r) * ldk + k0 + c] = t[c][r];
+}
+
+// The bf16 step's weight copies, one launch for all hidden layers (the step's preparation launch when the caller's
+// update call has not refreshed them; ultr_clip_adagrad_fused does): W_j -> Wp_j[(k / 4)][n][k % 4] and, for j >= 1,
+// W_j^T -> WTp_j[(n / 4)][k][n % 4], rounded to nearest even.  Rows beyond the matrix stay zero (zeroed workspace).
+struct PackArgs {
+  int n; const float* W[ULTR_MAX_LAYERS]; unsigned short* Wp[ULTR_MAX_LAYERS]; unsigned short* WTp[ULTR_MAX_LAYERS];
+  int K[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS];
+  long long start[ULTR_MAX_LAYERS + 1];  // in float4 units
+};
+__global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs p) {
+  const long long total = p.start[p.n];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int j = 0;
+    while (j + 1 < p.n && i >= p.start[j + 1]) ++j;
+    const long long rel = (i - p.start[j]) << 2;
+    const int ldn = p.ldn[j], k = (int)(rel / ldn), n0 = (int)(rel - (long long)k * ldn);
+    const float4 v = *reinterpret_cast<const float4*>(p.W[j] + rel);
+    pack_store(p.Wp[j], p.WTp[j], k, n0, ldn, (p.K[j] + 3) & ~3, v.x, v.y, v.z, v.w);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -972,6 +1035,8 @@ struct FusedPlan {
   size_t smem_bytes;
   // workspace (floats)
   long long xhat[ULTR_MAX_LAYERS], dz[ULTR_MAX_LAYERS], wt[ULTR_MAX_LAYERS], gslab[ULTR_MAX_LAYERS], sslab[ULTR_MAX_LAYERS], outpart;
+  long long wp[ULTR_MAX_LAYERS], wtp[ULTR_MAX_LAYERS];  // packed bf16 copies (compute_dtype bf16 only)
+  bool bf16;
   int nsplit, rows_per_split;
   long long total;
   bool ok;
@@ -981,6 +1046,7 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   FusedPlan P{};
   P.ok = false;
   P.H = d->n_layers - 1;
+  P.bf16 = d->compute_dtype == ULTR_DTYPE_BF16;
   if (P.H < 1 || L < 1 || L > 16 || B < 1) return P;
   P.nl = 16 / L;
   if (P.nl > 4) P.nl = 4;  // one 16-lane group per list in the loss lanes of a wave
@@ -1027,7 +1093,9 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   for (int j = 0; j < P.H; ++j) {
     P.xhat[j] = take(Mpad * round4(P.K[j]));
     P.dz[j] = take(Mpad * P.ldn[j]);
-    P.wt[j] = j >= 1 ? take((long long)P.N[j] * round4(P.K[j])) : 0;
+    P.wt[j] = j >= 1 && !P.bf16 ? take((long long)P.N[j] * round4(P.K[j])) : 0;
+    P.wp[j] = P.bf16 ? take((long long)((P.K[j] + 15) & ~15) * P.ldn[j] / 2) : 0;
+    P.wtp[j] = P.bf16 && j >= 1 ? take((long long)((P.N[j] + 15) & ~15) * round4(P.K[j]) / 2) : 0;
     P.gslab[j] = take((long long)P.nsplit * P.K[j] * P.ldn[j]);
     P.sslab[j] = take((long long)P.nsplit * P.ldn[j]);
   }
@@ -1068,11 +1136,11 @@ extern "C" long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int
   return P.ok ? P.total * (long long)sizeof(float) : 0;
 }
 
-template <int RIDE, bool FAST, int NQ>
-static int launch_chain2(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
+template <int RIDE, bool FAST, int NQ, bool BF>
+static int launch_chain3(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(train_chain_kernel<RIDE, FAST, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(train_chain_kernel<RIDE, FAST, NQ, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       set_error("ultr_dnn_train_fused: cannot raise the dynamic LDS limit");
       return ULTR_EHIP;
@@ -1082,10 +1150,16 @@ static int launch_chain2(const TcArgs& a, int nwg, size_t smem, hipStream_t st) 
   long long pw = 0;
   for (int j = 0; j < a.H; ++j) pw += (long long)a.K[j] * a.N[j] + (j >= 1 ? (long long)a.K[j] * a.N[j] : 0);
   {
-    ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("train_chain_kernel/P%lld", pw) : "train_chain_kernel", st);
-    hipLaunchKernelGGL((train_chain_kernel<RIDE, FAST, NQ>), dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
+    ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern(BF ? "train_chain_kernel_bf16/P%lld" : "train_chain_kernel/P%lld", pw)
+                                             : "train_chain_kernel", st);
+    hipLaunchKernelGGL((train_chain_kernel<RIDE, FAST, NQ, BF>), dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
   }
   return check_launch("train_chain_kernel");
+}
+template <int RIDE, bool FAST, int NQ>
+static int launch_chain2(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
+  if (a.Wp[0]) return launch_chain3<RIDE, FAST, NQ, true>(a, nwg, smem, st);
+  return launch_chain3<RIDE, FAST, NQ, false>(a, nwg, smem, st);
 }
 // `fast`: the reference's default scorer (elu, layer normalisation), input width a multiple of 4, hidden widths multiples
 // of 16, and layer 0's last weight chunk readable up to the next multiple of 16 rows (decided by the caller)
@@ -1127,8 +1201,29 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   hipStream_t st = as_stream(stream);
   const int H = P.H;
 
-  // ---- transposed weights for the dgrad GEMMs, unless the caller's last update call left them current
-  if (H >= 2 && !wt_fresh) {
+  // ---- the streamed weight copies, unless the caller's last update call left them current: packed bf16 ...
+  if (P.bf16 && !wt_fresh) {
+    PackArgs t{};
+    t.n = H;
+    long long start = 0;
+    for (int j = 0; j < H; ++j) {
+      t.W[j] = params + desc->off_W[j];
+      t.Wp[j] = reinterpret_cast<unsigned short*>(ws + P.wp[j]);
+      t.WTp[j] = j >= 1 ? reinterpret_cast<unsigned short*>(ws + P.wtp[j]) : nullptr;
+      t.K[j] = P.K[j]; t.ldn[j] = P.ldn[j];
+      t.start[j] = start;
+      start += (long long)P.K[j] * P.ldn[j] / 4;
+    }
+    t.start[H] = start;
+    {
+      ultr::ProfScope prof_("pack_weights_kernel", st);
+      hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv(start, 256)), dim3(256), 0, st, t);
+    }
+    rc = check_launch("pack_weights_kernel");
+    if (rc) return rc;
+  }
+  // ... or (fp32) transposed ones for the dgrad GEMMs
+  if (!P.bf16 && H >= 2 && !wt_fresh) {
     TransposeArgs t{};
     t.n = H - 1;
     int start = 0;
@@ -1158,7 +1253,9 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
     a.K[j] = P.K[j]; a.N[j] = P.N[j]; a.ldn[j] = P.ldn[j];
     if (j < H) {
       a.xhat[j] = ws + P.xhat[j]; a.dz[j] = ws + P.dz[j];
-      a.WT[j] = j >= 1 ? ws + P.wt[j] : nullptr;
+      a.WT[j] = j >= 1 && !P.bf16 ? ws + P.wt[j] : nullptr;
+      a.Wp[j] = P.bf16 ? ws + P.wp[j] : nullptr;
+      a.WTp[j] = P.bf16 && j >= 1 ? ws + P.wtp[j] : nullptr;
       a.act_off[j] = P.act_off[j]; a.act_ps[j] = P.act_ps[j];
     }
   }
@@ -1173,7 +1270,7 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
                    : pl.kind == ULTR_RIDE_REM ? pl.rem.list_weights : nullptr;
   bool fast = desc->activation == ULTR_ACT_ELU && has_ln && (P.K[0] & 3) == 0;
   for (int j = 1; j <= H; ++j) fast = fast && (P.K[j] & 15) == 0;
-  fast = fast && desc->off_W[0] + (long long)((P.K[0] + 15) & ~15) * P.ldn[0] <= desc->n_params;
+  if (!P.bf16) fast = fast && desc->off_W[0] + (long long)((P.K[0] + 15) & ~15) * P.ldn[0] <= desc->n_params;
   if (pl.kind == ULTR_RIDE_DLA) rc = launch_chain<ULTR_RIDE_DLA>(a, P.nwg, P.smem_bytes, fast, st);
   else if (pl.kind == ULTR_RIDE_IPW) rc = launch_chain<ULTR_RIDE_IPW>(a, P.nwg, P.smem_bytes, fast, st);
   else if (pl.kind == ULTR_RIDE_REM) rc = launch_chain<ULTR_RIDE_REM>(a, P.nwg, P.smem_bytes, fast, st);
@@ -1280,10 +1377,12 @@ extern "C" int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, vo
     g_pending_assemble.on = false;
   }
   float* wsf = reinterpret_cast<float*>(workspace);
-  for (int j = 1; j < P.H; ++j) {
+  for (int j = P.bf16 ? 0 : 1; j < P.H; ++j) {
     const int t = o.tr.n++;
     o.tr.off[t] = desc->off_W[j]; o.tr.K[t] = P.K[j]; o.tr.N[t] = P.N[j]; o.tr.ldn[t] = P.ldn[j];
-    o.tr.dst[t] = wsf + P.wt[j];
+    o.tr.dst[t] = P.bf16 ? nullptr : wsf + P.wt[j];
+    o.tr.pk[t] = P.bf16 ? reinterpret_cast<unsigned short*>(wsf + P.wp[j]) : nullptr;
+    o.tr.pkt[t] = P.bf16 && j >= 1 ? reinterpret_cast<unsigned short*>(wsf + P.wtp[j]) : nullptr;
   }
   return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream);
 }

@@ -160,9 +160,12 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
         if (rel >= 0 && rel < (long long)o.tr.K[j] * o.tr.ldn[j]) {
           const int k = (int)(rel / o.tr.ldn[j]), n0 = (int)(rel - (long long)k * o.tr.ldn[j]);  // ldn % 4 == 0: one row
           const int ldk = (o.tr.K[j] + 3) & ~3;
+          if (o.tr.dst[j]) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (n0 + q < o.tr.N[j]) o.tr.dst[j][(long long)(n0 + q) * ldk + k] = tv[q];
+            for (int q = 0; q < 4; ++q)
+              if (n0 + q < o.tr.N[j]) o.tr.dst[j][(long long)(n0 + q) * ldk + k] = tv[q];
+          }
+          if (o.tr.pk[j] || o.tr.pkt[j]) pack_store(o.tr.pk[j], o.tr.pkt[j], k, n0, o.tr.ldn[j], ldk, tv[0], tv[1], tv[2], tv[3]);
         }
       }
     }

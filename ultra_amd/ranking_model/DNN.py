@@ -31,7 +31,8 @@ class DNN(BaseRankingModel):
             activation_func='elu',               # elu, relu, selu, sigmoid or tanh
             initializer='None',                  # 'constant' -> 0.001
             norm='layer',                        # 'layer' | 'batch' | anything else: none
-            output_size=1)
+            output_size=1,
+            compute_dtype='f32')                 # (new) 'bf16': opt-in fast path of the fused training step
         self.hparams.parse(hparams_str)
         self.act_func = BaseRankingModel.ACT_FUNC_DIC.get(self.hparams.activation_func)
         self.initializer = BaseRankingModel.INITIALIZER_DIC.get(self.hparams.initializer)
@@ -75,6 +76,9 @@ class DNN(BaseRankingModel):
         d.activation = self.act_func
         d.norm = _lib.NORM_LAYER if self.hparams.norm == 'layer' else _lib.NORM_NONE
         d.ln_eps = LN_EPS
+        if self.hparams.compute_dtype not in ('f32', 'bf16'):
+            raise ValueError("compute_dtype '%s' unknown (f32, bf16)" % self.hparams.compute_dtype)
+        d.compute_dtype = _lib.DTYPE_BF16 if self.hparams.compute_dtype == 'bf16' else _lib.DTYPE_F32
         off = 0
         self.slices = []
         for j, (k, n) in enumerate(shapes):
