@@ -82,10 +82,11 @@ enum { ULTR_PROB_SOFTMAX = 0, ULTR_PROB_SIGMOID = 1 };
 /* grad_strategy hparam (dla.py:183-185) */
 enum { ULTR_OPT_ADAGRAD = 0, ULTR_OPT_SGD = 1 };
 /* compute_dtype hparam of the scorer (new; DNN.py:85-93 is the matmul it applies to).  F32: fp32 MFMA, the parity path.
- * BF16: opt-in fast path -- the forward and dgrad GEMMs of the hidden layers multiply bf16-rounded operands (activations
- * rounded on the fly, weights from packed bf16 copies that the update launch keeps current) and accumulate in fp32;
- * LayerNorm, activations, losses, the output layer, the weight gradients' accumulation and the optimiser stay fp32, and
- * the parameters are fp32 master copies.  Stated error bound: DESIGN.md section 3. */
+ * BF16: opt-in fast path -- the forward, dgrad and weight-gradient GEMMs of the hidden layers multiply bf16-rounded
+ * operands (activations and gradients rounded on the fly, weights from packed bf16 copies that the update launch keeps
+ * current) and accumulate in fp32; LayerNorm, activations, losses, the output layer, the split-K reduction and the
+ * optimiser stay fp32, what the step writes to memory stays fp32, and the parameters are fp32 master copies.
+ * Stated error bound: DESIGN.md section 3. */
 enum { ULTR_DTYPE_F32 = 0, ULTR_DTYPE_BF16 = 1 };
 /* metric bits for ultr_metrics */
 enum { ULTR_METRIC_MRR = 1, ULTR_METRIC_NDCG = 2, ULTR_METRIC_ERR = 4 };

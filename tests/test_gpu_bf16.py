@@ -1,5 +1,5 @@
 """GPU tests (-m gpu) of the opt-in bf16 fast path of the fused training step (ranking_model hparam compute_dtype=bf16:
-forward and dgrad GEMMs of the hidden layers on bf16 MFMA with fp32 accumulation; everything else fp32, fp32 master
+forward, dgrad and weight-gradient GEMMs of the hidden layers on bf16 MFMA with fp32 accumulation; everything else fp32, fp32 master
 parameters).  The reference has no reduced-precision path (DNN.py:85-93 is a float32 matmul), so the bound is this
 framework's own, stated in DESIGN.md section 3 and enforced here against the float64 oracle (oracle/torch_graph.py) on
 the three data-set widths of BASELINE.json:

@@ -895,6 +895,10 @@ constexpr size_t kWgRingBytes = sizeof(float) * kWgStages * kWgSlot;
 
 #define ULTR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// BF (the bf16 step): the same ring of fp32 tiles; the operands are rounded to bf16 on their way from LDS to the
+// registers and multiplied by v_mfma_f32_32x32x16_bf16 (two per 32-row chunk instead of sixteen fp32 MFMAs), fp32 accumulate.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool BF>
 __device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int by, int bz, float* ring) {
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -931,6 +935,7 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int b
   float colsum = 0.f;
   const bool do_colsum = by == 0 && wr == 0;
   const int a_off = h * 64 + wr * 32 + l31, b_off = kWgTile + h * 64 + wc * 32 + l31;
+  const int a_off8 = 8 * h * 64 + wr * 32 + l31, b_off8 = kWgTile + 8 * h * 64 + wc * 32 + l31;
   for (int c = 0; c < nch; ++c) {
     // chunk c has landed once at most `ahead` younger chunks (4 DMA each) are still in flight
     const int ahead = min(kWgStages - 2, nch - 1 - c);
@@ -942,13 +947,31 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int b
     issue(c + kWgStages - 1);  // into the slot of chunk c - 1: every wave has multiplied it out (the barrier above)
     const float* slot = ring + (c % kWgStages) * kWgSlot;
     float a[16], b[16];
+    if (BF) {
+      // lane (l31, h) of MFMA s holds rows 16 s + 8 h + e (e = 0..7) of its column: a[8 s + e]
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      a[t] = slot[a_off + 128 * t];
-      b[t] = slot[b_off + 128 * t];
+      for (int t = 0; t < 16; ++t) {
+        const int row = 16 * (t >> 3) + (t & 7);
+        a[t] = slot[a_off8 + 64 * row];
+        b[t] = slot[b_off8 + 64 * row];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 ua = make_uint4(pk_bf16(a[8 * s2], a[8 * s2 + 1]), pk_bf16(a[8 * s2 + 2], a[8 * s2 + 3]),
+                                    pk_bf16(a[8 * s2 + 4], a[8 * s2 + 5]), pk_bf16(a[8 * s2 + 6], a[8 * s2 + 7]));
+        const uint4 ub = make_uint4(pk_bf16(b[8 * s2], b[8 * s2 + 1]), pk_bf16(b[8 * s2 + 2], b[8 * s2 + 3]),
+                                    pk_bf16(b[8 * s2 + 4], b[8 * s2 + 5]), pk_bf16(b[8 * s2 + 6], b[8 * s2 + 7]));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, ua), __builtin_bit_cast(wg_bf16x8, ub), acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        a[t] = slot[a_off + 128 * t];
+        b[t] = slot[b_off + 128 * t];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
     if (do_colsum) {
       float s4[4];
 #pragma unroll
@@ -976,7 +999,7 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int b
 
 // Every layer's weight-gradient GEMM in one launch: exactly the workgroups that fit the chip at once (two per CU).
 struct WgradAllArgs {
-  int n_layers, nsplit;
+  int n_layers, nsplit, bf16;
   WgradArgs g[ULTR_MAX_LAYERS];
   int start[ULTR_MAX_LAYERS + 1], gy[ULTR_MAX_LAYERS];
 };
@@ -987,7 +1010,8 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_all_kernel(WgradAllArgs p) 
   while (j + 1 < p.n_layers && id >= p.start[j + 1]) ++j;
   const int local = id - p.start[j];
   const int bx = local % p.nsplit, t = local / p.nsplit;
-  wgrad_lds_body(p.g[j], bx, t % p.gy[j], t / p.gy[j], ring);
+  if (p.bf16) wgrad_lds_body<true>(p.g[j], bx, t % p.gy[j], t / p.gy[j], ring);
+  else wgrad_lds_body<false>(p.g[j], bx, t % p.gy[j], t / p.gy[j], ring);
 }
 
 // The slab reduction, with the step's latency-bound side jobs as rider workgroups (they come first): the in-step
@@ -1280,7 +1304,7 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   // ---- every weight-gradient GEMM + loss statistics + in-step metrics
   {
     WgradAllArgs g{};
-    g.n_layers = H; g.nsplit = P.nsplit;
+    g.n_layers = H; g.nsplit = P.nsplit; g.bf16 = P.bf16 ? 1 : 0;
     int start = 0;
     for (int j = 0; j < H; ++j) {
       WgradArgs& q = g.g[j];
@@ -1302,7 +1326,7 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
       wg_attr = true;
     }
     {
-      ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("wgrad_all_kernel/P%lld", [&] {
+      ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern(P.bf16 ? "wgrad_all_kernel_bf16/P%lld" : "wgrad_all_kernel/P%lld", [&] {
         long long s = 0; for (int j = 0; j < H; ++j) s += (long long)P.K[j] * P.N[j]; return s; }()) : "wgrad_all_kernel", st);
       hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)start), dim3(kThreads), kWgRingBytes, st, g);
     }

@@ -76,9 +76,10 @@ class DNN(BaseRankingModel):
         d.activation = self.act_func
         d.norm = _lib.NORM_LAYER if self.hparams.norm == 'layer' else _lib.NORM_NONE
         d.ln_eps = LN_EPS
-        if self.hparams.compute_dtype not in ('f32', 'bf16'):
-            raise ValueError("compute_dtype '%s' unknown (f32, bf16)" % self.hparams.compute_dtype)
-        d.compute_dtype = _lib.DTYPE_BF16 if self.hparams.compute_dtype == 'bf16' else _lib.DTYPE_F32
+        dtype = getattr(self.hparams, 'compute_dtype', 'f32')  # subclasses with their own hparams (Linear) have none
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("compute_dtype '%s' unknown (f32, bf16)" % dtype)
+        d.compute_dtype = _lib.DTYPE_BF16 if dtype == 'bf16' else _lib.DTYPE_F32
         off = 0
         self.slices = []
         for j, (k, n) in enumerate(shapes):
