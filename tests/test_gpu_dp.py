@@ -26,20 +26,22 @@ def make_rank(algo, data, exp, B, world, rank):
 
 
 CASES = [
-    ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 10),
-    ('DLA', '', 'hidden_layer_sizes=[512, 256, 128]', 136, 10),
-    ('IPWrank', 'propensity_estimator_json=%s' % IPW_JSON, 'hidden_layer_sizes=[64, 32]', 24, 10),
-    ('RegressionEM', '', 'hidden_layer_sizes=[64, 32]', 24, 10),
-    ('PairDebias', '', 'hidden_layer_sizes=[64, 32]', 24, 10),
-    ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 20),   # lists longer than 16: the per-launch plan
+    ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 10, 48),
+    ('DLA', '', 'hidden_layer_sizes=[512, 256, 128]', 136, 10, 48),
+    ('IPWrank', 'propensity_estimator_json=%s' % IPW_JSON, 'hidden_layer_sizes=[64, 32]', 24, 10, 48),
+    ('RegressionEM', '', 'hidden_layer_sizes=[64, 32]', 24, 10, 48),
+    ('PairDebias', '', 'hidden_layer_sizes=[64, 32]', 24, 10, 48),
+    ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 20, 48),   # lists longer than 16: the per-launch plan
+    # BASELINE config 4 (MSLR shape, 4096 lists per step): the whole step -- feed, step, update -- at full size; the
+    # 4096-list instance runs the per-launch plan, its 2048-list shards too (both beyond the fused step's row limit)
+    ('DLA', '', 'hidden_layer_sizes=[512, 256, 128]', 136, 10, 2048),
 ]
 
 
-@pytest.mark.parametrize('algo,hp,mhp,F,L', CASES)
-def test_two_ranks_on_one_gpu_equal_one_rank_with_the_whole_batch(algo, hp, mhp, F, L):
+@pytest.mark.parametrize('algo,hp,mhp,F,L,B', CASES)
+def test_two_ranks_on_one_gpu_equal_one_rank_with_the_whole_batch(algo, hp, mhp, F, L, B):
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
-    B = 48
-    data = SyntheticData(300, L, F, seed=5, pad_frac=0.2)
+    data = SyntheticData(300 if B < 1000 else 3000, L, F, seed=5, pad_frac=0.2)
     click = CASCADE if algo == 'PairDebias' else PBM
     exp = settings(algo, hp, mhp, Lmax=L, cutoff=L, feed_hparams='click_model_json=%s,seed=77' % click)
     whole, feed_w = make_rank(algo, data, exp, 2 * B, 1, 0)
@@ -122,3 +124,31 @@ def test_second_feed_on_a_model_shares_its_step_counter():
     m.step(None, fr, False)
     torch.cuda.synchronize()
     assert int(ctr.item()) > before
+
+
+def test_whole_step_at_4096_lists_against_the_float64_oracle():
+    """BASELINE config 4: feed -> step -> update at 4096 lists of 10 (MSLR width, DNN[512,256,128]) on the device against
+    the float64 restatement of the reference graph; loss and summaries 1e-5, parameters 3e-5 after the update."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    from tests.test_gpu_step import reference_for, torch_feed, tie_uniforms, compare_params, make
+    B, L, F = 4096, 10, 136
+    data = SyntheticData(3000, L, F, seed=6, pad_frac=0.1)
+    exp = settings('DLA', '', 'hidden_layer_sizes=[512, 256, 128]', Lmax=L, cutoff=L)
+    m, feed = make('DLA', data, exp, B)
+    hpd = {k: getattr(m.hparams, k) for k in ('learning_rate', 'max_gradient_norm', 'loss_func', 'logits_to_prob',
+                                               'propensity_learning_rate', 'ranker_loss_weight', 'l2_loss',
+                                               'max_propensity_weight', 'grad_strategy')}
+    pp = m.prop_params.cpu().numpy().astype(np.float64)
+    ref = reference_for('dla', m, L, hpd, prop_W=pp[:L, None], prop_b=pp[L:])
+    fd, _ = feed.get_batch(data, check_validation=True)
+    batch = fd[DEVICE_BATCH_KEY]
+    assert batch.B == B and (batch.labels.sum(dim=0) > 0).all()
+    u = tie_uniforms(m, np.random.RandomState(1), B, L)
+    loss, _, summary = m.step(None, fd, False)
+    ref_loss, ref_sum = ref.step(*torch_feed(data, batch), u_pred=u)
+    assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+    got = summary.as_dict()
+    for tag, val in ref_sum.items():
+        key = tag.replace(' ', '_')
+        assert abs(got[key] - val) <= 2e-5 * max(abs(val), 1e-2), (key, got[key], val)
+    compare_params(m, ref, 3e-5)

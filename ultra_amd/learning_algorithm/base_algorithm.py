@@ -381,9 +381,16 @@ class BaseAlgorithm(ABC):
     # ULTR_FUSED_STEP=0: forward, loss and backward pass as separate calls even for short lists
     fused_step = os.environ.get('ULTR_FUSED_STEP', '1') != '0'
 
+    # The fused step's workgroups own whole lists and each streams every weight: it wins while the batch fits the chip
+    # about three times over (measured crossover against the per-launch plan near 7.5 k rows: 97 against 131 us at
+    # 2560 rows, 1094 against 900 us at 40960); beyond that the per-layer kernels, which share weight tiles between
+    # workgroups, are the better plan.  ULTR_FUSED_MAX_ROWS overrides the threshold.
+    fused_max_rows = int(os.environ.get('ULTR_FUSED_MAX_ROWS', '8192'))
+
     def _fused_ok(self, batch):
         """Short lists run forward + loss gradient + backward as ONE call (ultr_dnn_train_fused)."""
-        return self.fused_step and self._loss_rides() and self.model.fused_supported(batch.B, batch.L)
+        return self.fused_step and self._loss_rides() and batch.B * batch.L <= self.fused_max_rows and \
+            self.model.fused_supported(batch.B, batch.L)
 
     def _step_local_fused(self, tb, batch):
         scores = tb['scores']
