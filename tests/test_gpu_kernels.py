@@ -278,7 +278,7 @@ def _loss_ws(L, B, Ls):
     return keep(torch.zeros(L.lib().ultr_loss_workspace_floats(B, Ls), dtype=torch.float32, device='cuda'))
 
 
-@pytest.mark.parametrize('B,Ls', [(256, 10), (1000, 9), (3, 1), (5000, 16)])
+@pytest.mark.parametrize('B,Ls', [(256, 10), (1000, 9), (3, 1), (5000, 16), (40000, 10), (300, 24), (70000, 20)])  # L > 16: list per thread, capped grid
 @pytest.mark.parametrize('loss_func,prob,maxw', [(0, 0, -1.0), (1, 0, -1.0), (0, 1, 3.0)])
 def test_dla_loss_kernel(L, B, Ls, loss_func, prob, maxw):
     rng = np.random.RandomState(B + Ls)
@@ -441,7 +441,8 @@ def test_sort_permutation_bit_exact_with_ties(L, B, Lx):
     assert np.array_equal(got, O.sort_permutation(scores, None, None))
 
 
-@pytest.mark.parametrize('B,Lx', [(256, 10), (100, 9), (33, 40), (6, 300)])
+@pytest.mark.parametrize('B,Lx', [(256, 10), (100, 9), (33, 40), (6, 300),
+                                  (40000, 10), (33001, 7), (32768, 16)])  # from 32768 lists on: one lane per list
 def test_metrics_kernel(L, B, Lx):
     from ultra_amd.utils import metrics as M
     rng = np.random.RandomState(B)

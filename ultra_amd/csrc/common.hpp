@@ -172,7 +172,20 @@ __device__ __forceinline__ void reduce_rows(const float* __restrict__ rows, int 
   const bool is_max = s >= max_from;
   float acc = is_max ? -INFINITY : 0.f;
   if (rg < RG) {
-    for (int b0 = rg; b0 < G; b0 += 4 * RG) {
+    int b0 = rg;
+    // long walks (thousands of rows: the large-batch loss and metric kernels) keep 16 loads in flight per thread
+    for (; b0 + 12 * RG < G; b0 += 16 * RG) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float* src = rows + (long long)min(b0 + u * RG, G - 1) * ns + s;
+        v[u] = SC1 ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (b0 + u * RG < G) acc = is_max ? fmaxf(acc, v[u]) : acc + v[u];
+    }
+    for (; b0 < G; b0 += 4 * RG) {
       float v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

@@ -101,19 +101,7 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
       s_logp[ULTR_MAX_LIST];
   BlockStats bs{s_part};
   const int tid = threadIdx.x;
-  const int b = blockIdx.x * blockDim.x + tid;
-  const bool on = b < B;
-  // issue every global load of this list up front (independent loads, one round trip)
-  float o[LT], c[LT];
-#pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    o[l] = 0.f;
-    c[l] = 0.f;
-    if (l < L && on) {
-      o[l] = scores[(long long)l * B + b];
-      c[l] = clicks[(long long)l * B + b];
-    }
-  }
+  bs.clear(4 + 3 * L);
   // propensity tower: one-hot(position) @ W_0 + b_0 -> ELU  (dla.py:264-304): logit_l = ELU(W[l]+b)
   if (tid < L) {
     const float pre = prop_params[tid] + prop_params[L];
@@ -138,6 +126,21 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
   }
   __syncthreads();
 
+  // The grid is capped (the last workgroup adds one partial row per workgroup): a thread walks lists b, b + grid, ...
+  for (long long b0 = (long long)blockIdx.x * blockDim.x; b0 < B; b0 += (long long)gridDim.x * blockDim.x) {
+  const long long b = b0 + tid;
+  const bool on = b < B;
+  // issue every global load of this list up front (independent loads, one round trip)
+  float o[LT], c[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    o[l] = 0.f;
+    c[l] = 0.f;
+    if (l < L && on) {
+      o[l] = scores[(long long)l * B + b];
+      c[l] = clicks[(long long)l * B + b];
+    }
+  }
   float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f, lw = 0.f;
   float m = -INFINITY, mean = 0.f, se = 0.f, S = 0.f;
 #pragma unroll
@@ -147,13 +150,18 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
       mean += o[l];
     }
   mean /= (float)L;
+  float ex[LT];  // exp(o_l - max): evaluated once, shared by the softmax, the relevance weights and the gradient
 #pragma unroll
-  for (int l = 0; l < LT; ++l)
+  for (int l = 0; l < LT; ++l) {
+    ex[l] = 0.f;
     if (l < L) {
-      se += expf(o[l] - m);
+      ex[l] = expf(o[l] - m);
+      se += ex[l];
       S += (c[l] + 0.0000001f) * s_pw[l];
     }
-  const float p0 = prob_kind == ULTR_PROB_SOFTMAX ? expf(o[0] - m) / se : sigmoidf_(o[0] - mean);
+  }
+  const float inv_se = 1.f / se;
+  const float p0 = prob_kind == ULTR_PROB_SOFTMAX ? ex[0] * inv_se : sigmoidf_(o[0] - mean);
   const float lse = m + logf(se);
 #pragma unroll
   for (int l = 0; l < LT; ++l) {
@@ -161,13 +169,13 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
       float rw = 0.f, col = 0.f;
       if (on) {
         const long long e = (long long)l * B + b;
-        const float pl = prob_kind == ULTR_PROB_SOFTMAX ? expf(o[l] - m) / se : sigmoidf_(o[l] - mean);
+        const float pl = prob_kind == ULTR_PROB_SOFTMAX ? ex[l] * inv_se : sigmoidf_(o[l] - mean);
         rw = clip_w(p0 / pl, max_pw);  // relevance weights (dla.py:159-160)
         lw += s_pw[l] * fminf(fmaxf(c[l], 0.f), 1.f);
         if (loss_func == ULTR_LOSS_SOFTMAX) {
           const float wl = (c[l] + 0.0000001f) * s_pw[l];
           rank_num -= wl * (o[l] - lse);
-          d_scores[e] = expf(o[l] - lse) * S - wl;
+          d_scores[e] = ex[l] * inv_se * S - wl;
           const float wle = (c[l] + 0.0000001f) * rw;
           exam_num -= wle * s_logp[l];
           exam_den += wle;
@@ -180,8 +188,8 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
           col = (sigmoidf_(s_logit[l]) - z) * rw;  // d exam/d logit_l directly
         }
       }
-      bs.add(4 + L + l, rw);
-      bs.add(4 + 2 * L + l, col);
+      bs.accumulate(4 + L + l, rw);
+      bs.accumulate(4 + 2 * L + l, col);
     }
   }
   if (on) {
@@ -189,10 +197,11 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_kernel(
     if (loss_func != ULTR_LOSS_SOFTMAX) exam_den = 1.f;
     if (list_weights) list_weights[b] = lw / (float)L;
   }
-  bs.add(0, rank_num);
-  bs.add(1, rank_den);
-  bs.add(2, exam_num);
-  bs.add(3, exam_den);
+  bs.accumulate(0, rank_num);
+  bs.accumulate(1, rank_den);
+  bs.accumulate(2, exam_num);
+  bs.accumulate(3, exam_den);
+  }
   bs.combine(s_acc, 4 + 3 * L, 1 << 30);
   __syncthreads();
   if (tid < L) s_acc[4 + tid] = 0.f;  // pw_l is batch independent: written once by the last block
@@ -600,16 +609,24 @@ extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, in
   if (rc) return rc;
   rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
   if (rc) return rc;
+  // Short lists: a 16-lane group per list (every lane busy: one exp per lane instead of L per thread).  Measured at
+  // 2^20 lists of 10: 98 us against 139 us for the list-per-thread kernel below (222 VGPRs, two waves per SIMD).
   if (L <= 16) {
     PendingLoss p{};
     p.kind = ULTR_RIDE_DLA; p.dla = a; p.nblocks = small_blocks(B);
     return launch_loss_now(p, as_stream(stream));
   }
+  const unsigned dla_blocks = (unsigned)(cdiv(B, kLossThreads) < 1024 ? cdiv(B, kLossThreads) : 1024);
   {
     ultr::ProfScope prof_("dla_loss_kernel", as_stream(stream));
-    hipLaunchKernelGGL(dla_loss_kernel<64>, dim3((unsigned)cdiv(B, kLossThreads)), dim3(kLossThreads), 0,
-                       as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
-                       max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
+    if (L <= 16)
+      hipLaunchKernelGGL(dla_loss_kernel<16>, dim3(dla_blocks), dim3(kLossThreads), 0,
+                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
+    else
+      hipLaunchKernelGGL(dla_loss_kernel<64>, dim3(dla_blocks), dim3(kLossThreads), 0,
+                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
   }
   return check_launch("dla_loss_kernel");
 }

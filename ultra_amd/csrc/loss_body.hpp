@@ -23,6 +23,14 @@ struct BlockStats {
     v = is_max ? wave_max(v) : wave_sum(v);
     if ((threadIdx.x & 63) == 0) s_part[(threadIdx.x >> 6) * kMaxStat + slot] = v;
   }
+  // the same for kernels whose threads walk several lists: the wave's row accumulates (clear() first)
+  __device__ __forceinline__ void clear(int ns) {
+    for (int s = threadIdx.x & 63; s < ns; s += 64) s_part[(threadIdx.x >> 6) * kMaxStat + s] = 0.f;
+  }
+  __device__ __forceinline__ void accumulate(int slot, float v) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_part[(threadIdx.x >> 6) * kMaxStat + slot] += v;
+  }
   __device__ __forceinline__ void combine(float* s_acc, int ns, int max_from) {
     __syncthreads();
     const int nw = blockDim.x >> 6;

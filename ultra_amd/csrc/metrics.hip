@@ -197,6 +197,143 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(MetricsArgs a) {
   metrics_finish(a, blockIdx.x, gridDim.x, s_vals, P <= 64 ? kMetThreads / 64 : LPB);
 }
 
+// Large batches of short lists (Lx <= 16, B >= kLanesMinB): ONE LANE PER LIST.  Consecutive lanes read consecutive
+// lists of the position-major arrays (fully coalesced, where the group-per-list mapping above touches 16 bytes of each
+// 128-byte line per load), a list's scores / labels / uniforms live in registers, and the positions come from
+// rank-by-counting over the list's pairs -- no lane ever talks to another before the final sums.
+constexpr int kLanesMinB = 32768, kLanesMaxBlocks = 2048;
+template <int LM, bool WANT_ERR>
+__global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs a) {
+  __shared__ float s_vals[4 * kMaxOut];
+  const float* __restrict__ scores = a.scores; const float* __restrict__ labels = a.labels;
+  const int* __restrict__ docids = a.docids; const float* __restrict__ list_weights = a.list_weights;
+  const float* __restrict__ u_pred = a.u_pred;
+  const int n_rows = a.n_rows, B = a.B, Lx = a.Lx, n_topn = a.n_topn, metric_mask = a.metric_mask;
+  const int topn[kMaxTopn] = {a.topn[0], a.topn[1], a.topn[2], a.topn[3], a.topn[4], a.topn[5], a.topn[6], a.topn[7]};
+  const bool want_mrr = (metric_mask & ULTR_METRIC_MRR) != 0, want_ndcg = (metric_mask & ULTR_METRIC_NDCG) != 0;
+  constexpr bool want_err = WANT_ERR;
+  const int n_met = (want_mrr ? 1 : 0) + (want_ndcg ? 1 : 0) + (want_err ? 1 : 0);
+  const int nout = n_met * n_topn * 2;
+  const float inv_pow = 1.f / powf(2.f, a.max_label);
+  const int tid = threadIdx.x;
+  // the wave's row of partial sums lives in LDS (only the wave's first lane touches it): 48 accumulators per lane would
+  // cost the kernel an occupancy step
+  float* my_row = s_vals + (tid >> 6) * nout;
+  if ((tid & 63) < nout) my_row[tid & 63] = 0.f;
+  for (long long b0 = (long long)blockIdx.x * kMetThreads; b0 < B; b0 += (long long)gridDim.x * kMetThreads) {
+    const bool on = b0 + tid < B;
+    const long long b = on ? b0 + tid : B - 1;  // idle lanes redo the last list and contribute nothing
+    float s[LM], lab[LM], u[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l) {
+      s[l] = -INFINITY; lab[l] = 0.f; u[l] = 0.f;
+      if (l < Lx) {
+        const long long g = (long long)l * B + b;
+        s[l] = scores[g];
+        if (docids && docids[g] == n_rows) s[l] = kPaddingScore;
+        lab[l] = labels[g];
+        if (u_pred) u[l] = u_pred[b * Lx + l];
+      }
+    }
+    const float w = list_weights ? list_weights[b] : 1.f;
+    // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
+    bool any_invalid = false;
+    float mn = INFINITY;
+#pragma unroll
+    for (int l = 0; l < LM; ++l)
+      if (l < Lx) {
+        any_invalid = any_invalid || lab[l] < 0.f;
+        mn = fminf(mn, s[l]);
+      }
+    if (any_invalid) {
+#pragma unroll
+      for (int l = 0; l < LM; ++l)
+        if (l < Lx && lab[l] < 0.f) {
+          lab[l] = 0.f;
+          s[l] = mn - 1e-6f;
+        }
+    }
+    // positions by counting over the pairs j < i: j goes first iff it wins (score desc, uniform asc, index asc)
+    int rank[LM], irank[LM];
+    float above[LM], omr[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l) {
+      rank[l] = 0; irank[l] = 0; above[l] = 1.f;
+      omr[l] = 1.f - (exp2f(lab[l]) - 1.f) * inv_pow;
+    }
+#pragma unroll
+    for (int i = 1; i < LM; ++i) {
+      if (i < Lx) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+          const bool jb = s[j] > s[i] || (s[j] == s[i] && u[j] <= u[i]);
+          rank[i] += jb ? 1 : 0;
+          rank[j] += jb ? 0 : 1;
+          if (want_ndcg) {
+            const bool jl = lab[j] >= lab[i];
+            irank[i] += jl ? 1 : 0;
+            irank[j] += jl ? 0 : 1;
+          }
+          if (want_err) {
+            above[i] *= jb ? omr[j] : 1.f;
+            above[j] *= jb ? 1.f : omr[i];
+          }
+        }
+      }
+    }
+    float mrr = 0.f, rel_sum = 0.f, dcg[kMaxTopn], idcg[kMaxTopn], err[kMaxTopn];
+#pragma unroll
+    for (int q = 0; q < kMaxTopn; ++q) dcg[q] = idcg[q] = err[q] = 0.f;
+#pragma unroll
+    for (int l = 0; l < LM; ++l) {
+      if (l < Lx) {
+        const float gain = exp2f(lab[l]) - 1.f;
+        rel_sum += gain;
+        if (lab[l] >= 1.f) mrr = fmaxf(mrr, 1.f / (float)(rank[l] + 1));
+        const float gd = gain / logf((float)rank[l] + 2.f), igd = gain / logf((float)irank[l] + 2.f);
+        // cumprod(1 - rel) / (1 - rel) as the reference writes it (metrics.py:312-314)
+        const float e_term = want_err ? (1.f - omr[l]) * ((above[l] * omr[l]) / omr[l]) / (float)(rank[l] + 1) : 0.f;
+#pragma unroll
+        for (int q = 0; q < kMaxTopn; ++q)
+          if (q < n_topn) {
+            if (want_ndcg) {
+              dcg[q] += rank[l] < topn[q] ? gd : 0.f;
+              idcg[q] += irank[l] < topn[q] ? igd : 0.f;
+            }
+            if (want_err) err[q] += rank[l] < topn[q] ? e_term : 0.f;
+          }
+      }
+    }
+    const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
+    const int mi_ndcg = want_mrr ? 1 : 0, mi_err = mi_ndcg + (want_ndcg ? 1 : 0);
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) {
+      if (o < nout) {
+        const int weighted = o & 1, q = (o >> 1) % n_topn, mi = (o >> 1) / n_topn;
+        float d = 0.f, idn = 0.f, er = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < kMaxTopn; ++qq)
+          if (qq == q) { d = dcg[qq]; idn = idcg[qq]; er = err[qq]; }
+        float val;
+        if (want_mrr && mi == 0) {
+          val = weighted ? mrr * w : mrr;
+        } else if (want_ndcg && mi == mi_ndcg) {
+          const float nd = idn != 0.f ? d / idn : 0.f;
+          const float ndw = (w * idn) != 0.f ? (w * d) / (w * idn) : 0.f;
+          val = weighted ? ndw * plw_w : nd * plw_plain;
+        } else {
+          (void)mi_err;
+          val = weighted ? er * w : er;
+        }
+        const float v = wave_sum(on ? val : 0.f);
+        if ((tid & 63) == 0) my_row[o] += v;
+      }
+    }
+  }
+  __syncthreads();
+  metrics_finish(a, blockIdx.x, gridDim.x, s_vals, kMetThreads / 64);
+}
+
 __global__ void __launch_bounds__(kMetThreads) sort_perm_kernel(const float* __restrict__ scores,
                                                                 const float* __restrict__ u, int B, int Lx, int P,
                                                                 int LPB, int topn, int* __restrict__ perm) {
@@ -248,6 +385,15 @@ int launch_metrics_now(const MetricsArgs& a, unsigned nblocks, hipStream_t st) {
                               96 * 1024);
     attr_set = true;
   }
+  if (a.P <= 16 && a.B >= kLanesMinB) {  // one lane per list (nblocks was sized for it by prepare_metrics)
+    ultr::ProfScope prof_("metrics_lanes_kernel", st);
+    const bool err = (a.metric_mask & ULTR_METRIC_ERR) != 0;
+    if (a.Lx <= 8 && err) hipLaunchKernelGGL((metrics_lanes_kernel<8, true>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
+    else if (a.Lx <= 8) hipLaunchKernelGGL((metrics_lanes_kernel<8, false>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
+    else if (err) hipLaunchKernelGGL((metrics_lanes_kernel<16, true>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
+    else hipLaunchKernelGGL((metrics_lanes_kernel<16, false>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
+    return check_launch("metrics_lanes_kernel");
+  }
   {
     ultr::ProfScope prof_("metrics_kernel", st);
     hipLaunchKernelGGL(metrics_kernel, dim3(nblocks), dim3(kMetThreads), metrics_smem(a), st, a);
@@ -278,6 +424,8 @@ static int prepare_metrics(const char* who, const float* scores, const float* la
   a->u_pred = u_pred; a->B = B; a->Lx = Lx; a->P = P; a->LPB = LPB; a->n_topn = n_topn;
   a->metric_mask = metric_mask; a->max_label = max_label; a->out = out; a->ws = ws;
   *nblocks = (unsigned)((P <= 64 && cdiv(B, LPB) > kMetMaxBlocks) ? kMetMaxBlocks : cdiv(B, LPB));
+  if (P <= 16 && B >= kLanesMinB)
+    *nblocks = (unsigned)(cdiv(B, kMetThreads) > kLanesMaxBlocks ? kLanesMaxBlocks : cdiv(B, kMetThreads));
   return ULTR_OK;
 }
 }  // namespace ultr
