@@ -70,6 +70,15 @@ struct TcArgs {
 
 struct TcFrag { float4 b[4]; };
 
+// The weight ring: kTcStages register stages per wave, kTcStages - 1 chunks of weights in flight while one is multiplied.
+// Measured: six stages (five 4 KB chunks per wave = 160 KB per CU in flight) run the kernel in 58.2 us against 57.2 with
+// four -- the stream is not short of loads in flight -- so four it is (-DULTR_TC_STAGES=6 builds the other).
+#ifndef ULTR_TC_STAGES
+#define ULTR_TC_STAGES 4
+#endif
+constexpr int kTcStages = ULTR_TC_STAGES;
+struct TcRing { TcFrag s[kTcStages]; };
+
 // Geometry of one 16-row GEMM  out[16][N] = A[16][K] . Wm[K][ld]  over the 8 waves of the workgroup: a wave owns units
 // of 64 output columns; fewer than 8 units split the contraction over the idle waves (KS slices, meeting in LDS).
 struct TcGeo {
@@ -151,39 +160,57 @@ template <bool BF> __device__ __forceinline__ unsigned tc_voff(const TcGeo& g, i
   return BF ? (unsigned)(2 * (kk * g.ld + colc)) : (unsigned)(4 * kk * g.ld + colc);
 }
 template <bool FAST, bool BF>
-__device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcFrag& S0, TcFrag& S1, TcFrag& S2) {
+__device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcRing& R) {
   if (g.u_first < g.U) {
     const int colc = min(64 * g.u_first + 4 * nn, g.ld - 4);
     const unsigned voff = tc_voff<BF>(g, colc, kk);
-    tc_wload<FAST, BF>(g, colc, voff, 0, kk, S0);
-    tc_wload<FAST, BF>(g, colc, voff, 1, kk, S1);
-    tc_wload<FAST, BF>(g, colc, voff, 2, kk, S2);
+#pragma unroll
+    for (int i = 0; i < kTcStages - 1; ++i) tc_wload<FAST, BF>(g, colc, voff, i, kk, R.s[i]);
   }
 }
 
-// Four-stage rotation: three chunks of weights in flight while one is multiplied.
 #define TC_SB() __builtin_amdgcn_sched_barrier(0)
-#define TC_STREAM4(NCH, LOAD, COMPUTE)                          \
-  do {                                                          \
-    int i_ = 0;                                                 \
-    for (; i_ + 4 <= (NCH); i_ += 4) {                          \
-      LOAD(i_ + 3, S3); TC_SB(); COMPUTE(S0, i_); TC_SB();      \
-      LOAD(i_ + 4, S0); TC_SB(); COMPUTE(S1, i_ + 1); TC_SB();  \
-      LOAD(i_ + 5, S1); TC_SB(); COMPUTE(S2, i_ + 2); TC_SB();  \
-      LOAD(i_ + 6, S2); TC_SB(); COMPUTE(S3, i_ + 3); TC_SB();  \
-    }                                                           \
-    if (i_ < (NCH)) COMPUTE(S0, i_);                            \
-    if (i_ + 1 < (NCH)) COMPUTE(S1, i_ + 1);                    \
-    if (i_ + 2 < (NCH)) COMPUTE(S2, i_ + 2);                    \
+#if ULTR_TC_STAGES == 4
+#define TC_STREAM(NCH, LOAD, COMPUTE)                                        \
+  do {                                                                       \
+    int i_ = 0;                                                              \
+    for (; i_ + 4 <= (NCH); i_ += 4) {                                       \
+      LOAD(i_ + 3, R.s[3]); TC_SB(); COMPUTE(R.s[0], i_); TC_SB();           \
+      LOAD(i_ + 4, R.s[0]); TC_SB(); COMPUTE(R.s[1], i_ + 1); TC_SB();       \
+      LOAD(i_ + 5, R.s[1]); TC_SB(); COMPUTE(R.s[2], i_ + 2); TC_SB();       \
+      LOAD(i_ + 6, R.s[2]); TC_SB(); COMPUTE(R.s[3], i_ + 3); TC_SB();       \
+    }                                                                        \
+    if (i_ < (NCH)) COMPUTE(R.s[0], i_);                                     \
+    if (i_ + 1 < (NCH)) COMPUTE(R.s[1], i_ + 1);                             \
+    if (i_ + 2 < (NCH)) COMPUTE(R.s[2], i_ + 2);                             \
   } while (0)
+#else
+#define TC_STREAM(NCH, LOAD, COMPUTE)                                        \
+  do {                                                                       \
+    int i_ = 0;                                                              \
+    for (; i_ + 6 <= (NCH); i_ += 6) {                                       \
+      LOAD(i_ + 5, R.s[5]); TC_SB(); COMPUTE(R.s[0], i_); TC_SB();           \
+      LOAD(i_ + 6, R.s[0]); TC_SB(); COMPUTE(R.s[1], i_ + 1); TC_SB();       \
+      LOAD(i_ + 7, R.s[1]); TC_SB(); COMPUTE(R.s[2], i_ + 2); TC_SB();       \
+      LOAD(i_ + 8, R.s[2]); TC_SB(); COMPUTE(R.s[3], i_ + 3); TC_SB();       \
+      LOAD(i_ + 9, R.s[3]); TC_SB(); COMPUTE(R.s[4], i_ + 4); TC_SB();       \
+      LOAD(i_ + 10, R.s[4]); TC_SB(); COMPUTE(R.s[5], i_ + 5); TC_SB();      \
+    }                                                                        \
+    if (i_ < (NCH)) COMPUTE(R.s[0], i_);                                     \
+    if (i_ + 1 < (NCH)) COMPUTE(R.s[1], i_ + 1);                             \
+    if (i_ + 2 < (NCH)) COMPUTE(R.s[2], i_ + 2);                             \
+    if (i_ + 3 < (NCH)) COMPUTE(R.s[3], i_ + 3);                             \
+    if (i_ + 4 < (NCH)) COMPUTE(R.s[4], i_ + 4);                             \
+  } while (0)
+#endif
 
 // The GEMM proper.  A: LDS panel [16][PS] (finite beyond K up to the next multiple of 16 in rows that matter: zero); once
 // multiplied out it serves as the split-K exchange buffer.  epi(u, acc) receives the finished unit:
 // acc[t][r] = out[row 4 kk + r][col 64 u + 4 nn + t].  The first three weight chunks of the wave's first unit must
-// already be in S0 / S1 / S2 (tc_prefetch).
+// already be in the ring (tc_prefetch).
 template <bool FAST, bool BF, class Epi>
-__device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn, int kk, int lane, TcFrag& S0,
-                                        TcFrag& S1, TcFrag& S2, TcFrag& S3, Epi epi, int stamp = -1) {
+__device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn, int kk, int lane, TcRing& R, Epi epi,
+                                        int stamp = -1) {
   if (stamp >= 0) TC_STAMP(stamp);
   const float* arow = A + nn * PS + 4 * kk + 16 * g.c_begin;
   for (int u = g.u_first; u < g.U; u += 8) {
@@ -193,9 +220,8 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
     const int colc = min(64 * u + 4 * nn, g.ld - 4);
     const unsigned voff = tc_voff<BF>(g, colc, kk);
     if (u != g.u_first) {
-      tc_wload<FAST, BF>(g, colc, voff, 0, kk, S0);
-      tc_wload<FAST, BF>(g, colc, voff, 1, kk, S1);
-      tc_wload<FAST, BF>(g, colc, voff, 2, kk, S2);
+#pragma unroll
+      for (int i = 0; i < kTcStages - 1; ++i) tc_wload<FAST, BF>(g, colc, voff, i, kk, R.s[i]);
     }
     float4 a_cur = *reinterpret_cast<const float4*>(arow);
     auto compute = [&](TcFrag& S, int i) {
@@ -222,7 +248,7 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
     };
 #define TC_LOAD(i, S) tc_wload<FAST, BF>(g, colc, voff, (i), kk, S)
 #define TC_COMPUTE(S, i) compute(S, (i))
-    TC_STREAM4(g.nch, TC_LOAD, TC_COMPUTE);
+    TC_STREAM(g.nch, TC_LOAD, TC_COMPUTE);
 #undef TC_LOAD
 #undef TC_COMPUTE
     if (stamp >= 0) TC_STAMP(stamp + 1);
@@ -294,7 +320,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   float* P2 = smem + p.p2_off;
   float* s_stat = smem + p.misc_off;                       // [layer][16][2]
   float* s_score = s_stat + (ULTR_MAX_LAYERS + 1) * 32;    // [16]
-  TcFrag S0, S1, S2, S3;
+  TcRing R;
   TC_STAMP(0);
 
   // ---- the wave's two rows, w and w + 8 (valid rows spread evenly over the SIMDs): local row rr = li * L + l  <->
@@ -313,7 +339,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   // ---- layer 0: weights first, then the rows (doc id -> table row + statistics: two dependent round trips)
   TcGeo g = tc_geo(BF ? p.Wp[0] : p.W[0], p.K[0], p.N[0], p.ldn[0], w);
   g.dbg = p.dbg;
-  tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
+  tc_prefetch<FAST, BF>(g, nn, kk, R);
   int docid[2];
 #pragma unroll
   for (int r2 = 0; r2 < 2; ++r2) docid[r2] = rvalid[r2] ? p.docids[re[r2]] : p.n_rows;
@@ -451,7 +477,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     float* actj = smem + p.act_off[j];
     const int aps = p.act_ps[j];
     const float* biasj = p.bias[j];
-    tc_gemm<FAST, BF>(g, P1, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
+    tc_gemm<FAST, BF>(g, P1, PS, nn, kk, lane, R, [&](int u, f32x4 (&acc)[4]) {
       const int col0 = 64 * u + 4 * nn;
       const int n16 = (N + 15) & ~15;
       const float4 b4 = *reinterpret_cast<const float4*>(biasj + min(col0, ((N + 3) & ~3) - 4));
@@ -471,7 +497,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     if (j + 1 < H) {  // the next layer's weight stream starts before its rows are normalised
       g = tc_geo(BF ? p.Wp[j + 1] : p.W[j + 1], p.K[j + 1], p.N[j + 1], p.ldn[j + 1], w);
       g.dbg = p.dbg;
-      tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
+      tc_prefetch<FAST, BF>(g, nn, kk, R);
     }
     lds_barrier();  // the layer's activations are complete
     TC_STAMP(3 + 3 * j);
@@ -717,7 +743,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   if (H >= 2) {
     g = tc_geo(BF ? p.WTp[H - 1] : p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w);
     g.dbg = p.dbg;
-    tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
+    tc_prefetch<FAST, BF>(g, nn, kk, R);
   }
   TC_STAMP(17);
   lds_barrier();
@@ -751,7 +777,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memtime();
 #endif
     if (j == 1) TC_WSTAMP(0);
-    tc_gemm<FAST, BF>(g, cur, PS, nn, kk, lane, S0, S1, S2, S3, [&](int u, f32x4 (&acc)[4]) {
+    tc_gemm<FAST, BF>(g, cur, PS, nn, kk, lane, R, [&](int u, f32x4 (&acc)[4]) {
       const int col0 = 64 * u + 4 * nn;
       if (col0 < K16) {
 #pragma unroll
@@ -762,7 +788,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     if (j >= 2) {  // the next layer's weight stream starts under the row pass
       g = tc_geo(BF ? p.WTp[j - 1] : p.WT[j - 1], p.N[j - 1], p.K[j - 1], (p.K[j - 1] + 3) & ~3, w);
       g.dbg = p.dbg;
-      tc_prefetch<FAST, BF>(g, nn, kk, S0, S1, S2);
+      tc_prefetch<FAST, BF>(g, nn, kk, R);
     }
 #ifdef ULTR_STAMPS
     if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memtime();

@@ -79,56 +79,9 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
           s = mn - 1e-6f;
         }
       }
-      const bool want_ideal = (metric_mask & ULTR_METRIC_NDCG) != 0;
-      const bool want_err = (metric_mask & ULTR_METRIC_ERR) != 0;
-      // What the metric sums need of the sort is, per document, its position in the ranking (and in the ideal ranking),
-      // never the permuted list itself.  pos / ipos: the position this lane's gain / ideal gain is discounted at;
-      // g_lab / g_ilab: the labels behind those gains; live: the lane holds a document.
-      int pos, ipos;
-      float g_lab, g_ilab, e_term = 0.f;
-      bool live;
-      const float inv_pow = 1.f / powf(2.f, max_label);
-      if (P <= 16) {
-        // Rank by counting: position = number of documents of the list that go before this one under the total order
-        // (score desc, uniform asc, index asc) -- the permutation of sort_by_scores (metric_utils.py:49-86), without
-        // moving anything.  The other documents come by as the 16-lane row rotates (DPP row_ror: VALU speed, no LDS
-        // round trips; the bitonic network below costs 40 ds_bpermute per list); lanes of other lists in the row are
-        // masked out.  The ideal position (labels descending) and ERR's product over the documents ranked above
-        // (metrics.py:312-314) accumulate in the same pass.
-        const int lane16 = tid & 15, gmask = (16 - P) & 15;
-        const int meta = id | (lane16 << 16);
-        const float omr = 1.f - (real ? (exp2f(lb) - 1.f) * inv_pow : 0.f);
-        int rank = 0, irank = 0;
-        float above = 1.f;
-#define ULTR_ROT_STEP(J)                                                                                              \
-        {                                                                                                             \
-          const float ps = ULTR_DPP_F(s, 0x120 + J), pu = ULTR_DPP_F(uu, 0x120 + J), pl = ULTR_DPP_F(lb, 0x120 + J);  \
-          const int pm = __builtin_amdgcn_update_dpp(0, meta, 0x120 + J, 0xF, 0xF, true);                             \
-          const int pid = pm & 0xFFFF;                                                                                \
-          const bool ok = (((pm >> 16) ^ lane16) & gmask) == 0 && pid < Lx;                                           \
-          const bool bef = ok && (ps > s || (ps == s && (pu < uu || (pu == uu && pid < id))));                        \
-          rank += bef ? 1 : 0;                                                                                        \
-          if (want_ideal) irank += (ok && (pl > lb || (pl == lb && pid < id))) ? 1 : 0;                               \
-          if (want_err) {                                                                                             \
-            const float po = ULTR_DPP_F(omr, 0x120 + J);                                                              \
-            above *= bef ? po : 1.f;                                                                                  \
-          }                                                                                                           \
-        }
-        ULTR_ROT_STEP(1) ULTR_ROT_STEP(2) ULTR_ROT_STEP(3) ULTR_ROT_STEP(4) ULTR_ROT_STEP(5)
-        ULTR_ROT_STEP(6) ULTR_ROT_STEP(7) ULTR_ROT_STEP(8) ULTR_ROT_STEP(9) ULTR_ROT_STEP(10)
-        ULTR_ROT_STEP(11) ULTR_ROT_STEP(12) ULTR_ROT_STEP(13) ULTR_ROT_STEP(14) ULTR_ROT_STEP(15)
-#undef ULTR_ROT_STEP
-        live = real;
-        pos = rank; ipos = irank;
-        g_lab = g_ilab = real ? lb : 0.f;
-        if (want_err) {
-          const float rel = 1.f - omr;
-          // cumprod(1 - rel) / (1 - rel) as the reference writes it (NaN for a document of the maximum grade, :314)
-          e_term = live ? rel * ((above * omr) / omr) / (float)(rank + 1) : 0.f;
-        }
-      } else {
       const float lab_orig = lb;  // label of the document at ORIGINAL position r
       float il = real ? lb : -INFINITY;
+      const bool want_ideal = (metric_mask & ULTR_METRIC_NDCG) != 0;
       for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
           const float ps = __shfl_xor(s, j, 64), pu = __shfl_xor(uu, j, 64);
@@ -152,12 +105,21 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
       r_lab = __shfl(lab_orig, src_lane, 64);
       if (id >= Lx) r_lab = 0.f;
       r_ilab = il;
-      live = r < Lx;
-      pos = ipos = r;
-      g_lab = live ? r_lab : 0.f;
-      g_ilab = live ? r_ilab : 0.f;
-      if (want_err) {
-        const float rel = (live ? exp2f(g_lab) - 1.f : 0.f) * inv_pow;  // metrics.py:312-313
+      // short lists: one lane per (list, rank); a list is a P-lane group inside one wave, so sums, maxima and
+      // the ERR prefix product are shuffles within the group -- no serial walk, every lane busy
+      const bool live = r < Lx;
+      const float lbr = live ? r_lab : 0.f;
+      const float ilr = live ? r_ilab : 0.f;
+      const float gain = live ? exp2f(lbr) - 1.f : 0.f, igain = live ? exp2f(ilr) - 1.f : 0.f;
+      const float disc = logf((float)r + 2.f);
+      const float gd = gain / disc, igd = igain / disc;
+      auto gsum = [&](float v) { return group_sum_rt(v, P); };
+      const float rel_sum = gsum(gain);
+      float mrr = (live && lbr >= 1.f) ? 1.f / (float)(r + 1) : 0.f;
+      mrr = group_max_rt(mrr, P);
+      float e_term = 0.f;
+      if (metric_mask & ULTR_METRIC_ERR) {
+        const float rel = gain / powf(2.f, max_label);  // metrics.py:312-313
         float cum = live ? 1.f - rel : 1.f;             // inclusive prefix product within the group
         for (int o = 1; o < P; o <<= 1) {
           const float up = __shfl_up(cum, o, 64);
@@ -165,25 +127,17 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
         }
         e_term = live ? rel * (cum / (1.f - rel)) / (float)(r + 1) : 0.f;  // cumprod/(1-rel) (:314)
       }
-      }
-      // one lane per document; a list is a P-lane group inside one wave, so sums and maxima are lane exchanges within
-      // the group -- no serial walk, every lane busy
-      const float gain = live ? exp2f(g_lab) - 1.f : 0.f, igain = live ? exp2f(g_ilab) - 1.f : 0.f;
-      const float gd = gain / logf((float)pos + 2.f), igd = igain / logf((float)ipos + 2.f);
-      auto gsum = [&](float v) { return group_sum_rt(v, P); };
-      const float rel_sum = gsum(gain);
-      float mrr = (live && g_lab >= 1.f) ? 1.f / (float)(pos + 1) : 0.f;
-      mrr = group_max_rt(mrr, P);
       float dcg[kMaxTopn], idcg[kMaxTopn], err[kMaxTopn];
   #pragma unroll
       for (int q = 0; q < kMaxTopn; ++q) {
         dcg[q] = idcg[q] = err[q] = 0.f;
         if (q < n_topn) {
+          const bool in = r < topn[q];
           if (metric_mask & ULTR_METRIC_NDCG) {
-            dcg[q] = gsum(pos < topn[q] ? gd : 0.f);
-            idcg[q] = gsum(ipos < topn[q] ? igd : 0.f);
+            dcg[q] = gsum(in ? gd : 0.f);
+            idcg[q] = gsum(in ? igd : 0.f);
           }
-          if (metric_mask & ULTR_METRIC_ERR) err[q] = gsum(pos < topn[q] ? e_term : 0.f);
+          if (metric_mask & ULTR_METRIC_ERR) err[q] = gsum(in ? e_term : 0.f);
         }
       }
       // The list's sums are uniform over its P lanes, so lane r forms output o = r (r + P, ...) of the list instead of
