@@ -221,6 +221,12 @@ def main():
     ap.add_argument('--no_profile', action='store_true')
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when its first
+    # communicator comes up), so file descriptor 1 is pointed at stderr for the run and the line goes to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -396,7 +402,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, args, data, model)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -68,8 +68,11 @@ extern "C" {
 
 /* activation_func (base_ranking_model.py:59-65) */
 enum { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1, ULTR_ACT_SELU = 2, ULTR_ACT_TANH = 3, ULTR_ACT_SIGMOID = 4 };
-/* norm hparam (DNN.py:32,70): "layer" or anything else = no normalisation */
-enum { ULTR_NORM_NONE = 0, ULTR_NORM_LAYER = 1 };
+/* norm hparam (DNN.py:32,70-84; base_ranking_model.py:67-70): "layer", "batch", or anything else = no normalisation.
+ * BATCH: keras BatchNormalization called with training = true -- batch statistics over all M rows of the call
+ * (biased variance, epsilon = ln_eps); the training passes use it.  BATCH_EVAL: training = false -- the moving
+ * statistics, which the reference's training step never updates (mean 0, variance 1); forward only. */
+enum { ULTR_NORM_NONE = 0, ULTR_NORM_LAYER = 1, ULTR_NORM_BATCH = 2, ULTR_NORM_BATCH_EVAL = 3 };
 /* click models on the device path (click_models.py:74-116 PBM, :194-241 cascade, :119-191 user browsing model;
  * TABLE = any model whose click probability is a function of (relevance grade, rank) only, handed over as that
  * table: the trust-bias model :273-322 and the click-matrix model :244-270) */

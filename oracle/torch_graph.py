@@ -44,6 +44,16 @@ def dnn_build(params, input_list, activation='elu', norm='layer'):
     for j, p in enumerate(params):
         if norm == 'layer':
             x = F.layer_norm(x, (x.shape[-1],), p['gamma'], p['beta'], LN_EPS)
+        elif norm == 'batch':
+            # keras BatchNormalization(training=True) on [M, K] (DNN.py:82-84): tf.nn.moments over the rows (biased
+            # variance), epsilon 1e-3, then tf.nn.batch_normalization
+            mean = x.mean(dim=0, keepdim=True)
+            var = ((x - mean) ** 2).mean(dim=0, keepdim=True)
+            x = (x - mean) * torch.rsqrt(var + LN_EPS) * p['gamma'] + p['beta']
+        elif norm == 'batch_eval':
+            # training=False: the moving statistics.  The reference's training step never runs the layer's update
+            # ops (dla.py:237-255 fetches the optimiser's only), so they keep their initial values: mean 0, variance 1
+            x = x * (1.0 / math.sqrt(1.0 + LN_EPS)) * p['gamma'] + p['beta']
         x = x @ p['W'] + p['b']
         if j != n - 1:
             x = act(x)
@@ -239,7 +249,7 @@ class TorchReferenceStep(object):
         out = []
         for p in self.params:
             out += [p['W'], p['b']]
-            if self.norm == 'layer':
+            if self.norm in ('layer', 'batch'):
                 out += [p['gamma'], p['beta']]
         return out
 

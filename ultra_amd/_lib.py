@@ -14,7 +14,7 @@ ULTR_MAX_LAYERS = 8
 ULTR_MAX_LIST = 64
 
 ACT = {'elu': 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid': 4}
-NORM_NONE, NORM_LAYER = 0, 1
+NORM_NONE, NORM_LAYER, NORM_BATCH, NORM_BATCH_EVAL = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16 = 0, 1
 CLICK_PBM, CLICK_CASCADE, CLICK_ORACLE, CLICK_TABLE, CLICK_UBM = 0, 1, 2, 3, 4
 LOSS_SOFTMAX, LOSS_SIGMOID = 0, 1

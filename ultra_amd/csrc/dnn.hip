@@ -58,6 +58,11 @@ struct Layout {
   int out_rows_per_block, out_blocks;
   long long outpart;                   // [out_blocks][3*Kout + 4]
   int maxld;
+  // batch normalisation only (bn_body.hpp): column statistics per layer, the scratch of the column sums, the
+  // normalised-and-scaled input `a` of the layer being run, xhat of the output layer's input
+  bool bn;
+  long long cstat[ULTR_MAX_LAYERS + 1];  // [K_j][2] (mean, rstd)
+  long long c12, bn_part, bn_a, xhat_out;
   long long total;
 };
 
@@ -113,6 +118,19 @@ static Layout make_layout(const UltrDnnDesc* d, long long M) {
   L.out_rows_per_block = (int)rpb;
   L.out_blocks = (int)cdiv(M, rpb);
   L.outpart = take((long long)L.out_blocks * (3 * L.K[L.H] + 4));
+  L.bn = d->norm == ULTR_NORM_BATCH || d->norm == ULTR_NORM_BATCH_EVAL;
+  L.c12 = L.bn_part = L.bn_a = L.xhat_out = 0;
+  if (L.bn) {
+    int maxk = 4;
+    for (int j = 0; j <= L.H; ++j) {
+      L.cstat[j] = take(2ll * L.K[j]);
+      if (round4(L.K[j]) > maxk) maxk = round4(L.K[j]);
+    }
+    L.c12 = take(2ll * maxk);
+    L.bn_part = take(2ll * 64 * maxk);  // kBnSplits row splits
+    L.bn_a = take(M * maxk);
+    L.xhat_out = take(M * round4(L.K[L.H]));
+  }
   L.total = off;
   return L;
 }
@@ -1723,6 +1741,8 @@ static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st, const c
   return launch_fwd<1, 4, false>(a, st, name);
 }
 
+#include "bn_body.hpp"
+
 int ultr_check_desc(const UltrDnnDesc* d, const char* who) {
   ULTR_REQUIRE(d, ULTR_EINVAL, "%s: null descriptor", who);
   ULTR_REQUIRE(d->n_layers >= 1 && d->n_layers <= ULTR_MAX_LAYERS, ULTR_ELIMIT, "%s: n_layers=%d not in [1,%d]", who,
@@ -1735,8 +1755,7 @@ int ultr_check_desc(const UltrDnnDesc* d, const char* who) {
                  who, d->sizes[j], ULTR_MAX_WIDTH);
   ULTR_REQUIRE(d->activation >= ULTR_ACT_ELU && d->activation <= ULTR_ACT_SIGMOID, ULTR_EINVAL, "%s: activation=%d",
                who, d->activation);
-  ULTR_REQUIRE(d->norm == ULTR_NORM_NONE || d->norm == ULTR_NORM_LAYER, ULTR_EINVAL,
-               "%s: norm=%d (batch normalisation is not on the device path)", who, d->norm);
+  ULTR_REQUIRE(d->norm >= ULTR_NORM_NONE && d->norm <= ULTR_NORM_BATCH_EVAL, ULTR_EINVAL, "%s: norm=%d", who, d->norm);
   ULTR_REQUIRE(d->compute_dtype == ULTR_DTYPE_F32 || d->compute_dtype == ULTR_DTYPE_BF16, ULTR_EINVAL,
                "%s: compute_dtype=%d", who, d->compute_dtype);
   for (int j = 0; j < d->n_layers; ++j)
@@ -1770,7 +1789,7 @@ int ultr_common_checks(const char* who, const UltrDnnDesc* desc, const float* pa
   int rc = ultr_check_desc(desc, who);
   if (rc) return rc;
   ULTR_REQUIRE(params && table && docids && workspace, ULTR_EINVAL, "%s: null pointer", who);
-  ULTR_REQUIRE(desc->norm == ULTR_NORM_NONE || table_stats, ULTR_EINVAL, "%s: table_stats required with norm=layer",
+  ULTR_REQUIRE(desc->norm != ULTR_NORM_LAYER || table_stats, ULTR_EINVAL, "%s: table_stats required with norm=layer",
                who);
   ULTR_REQUIRE(M > 0 && n_rows >= 0, ULTR_EINVAL, "%s: bad sizes M=%lld n_rows=%d", who, M, n_rows);
   ULTR_REQUIRE(ldx >= desc->in_features && (ldx & 3) == 0, ULTR_EINVAL,
@@ -1799,7 +1818,8 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
   // beyond that the per-layer kernels' 32-row tiles, which stream every weight half as often, are the better plan.
   // ULTR_FWD_CHAIN=1 forces the chain at any size.
   static const bool chain_force = [] { const char* e = getenv("ULTR_FWD_CHAIN"); return e && e[0] == '1'; }();
-  if (chain_on && (M <= 16384 || chain_force) && L.H >= 1 && L.K[0] <= 1024) {  // hidden widths are <= 1024 (check_desc)
+  const bool bn = L.bn, bn_train = desc->norm == ULTR_NORM_BATCH;  // batch normalisation: the per-layer plan (bn_body.hpp)
+  if (!bn && chain_on && (M <= 16384 || chain_force) && L.H >= 1 && L.K[0] <= 1024) {  // hidden widths are <= 1024 (check_desc)
     int maxw = L.K[0];
     for (int j = 0; j < L.H; ++j) maxw = L.N[j] > maxw ? L.N[j] : maxw;
     chain_ps = ((maxw + 31) & ~31) + 4;
@@ -1856,7 +1876,14 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
     a.K = L.K[j]; a.N = L.N[j]; a.ldn = L.ldn[j]; a.M = M; a.activation = desc->activation;
     a.act_out = ws + L.act[j];
     a.xhat_out = ws + L.xhat[j]; a.ldxh = round4(L.K[j]);
-    const bool fuse = j == L.H - 1 && j > 0 && L.N[j] <= 128;  // the last hidden layer also produces the scores
+    if (bn) {  // the normalised input comes from its own passes; the GEMM kernel runs as a plain layer on it
+      rc = bn_forward_input(a.x, a.ldx, a.docids, a.n_rows, L.K[j], round4(L.K[j]), M, desc->ln_eps, bn_train, a.gamma,
+                            a.beta, ws + L.cstat[j], ws + L.bn_part, ws + L.xhat[j], ws + L.bn_a, st);
+      if (rc) return rc;
+      a.x = ws + L.bn_a; a.ldx = round4(L.K[j]); a.docids = nullptr; a.n_rows = 0; a.row_stats = nullptr;
+      a.stat_out = nullptr; a.has_ln = 0; a.xhat_out = nullptr;
+    }
+    const bool fuse = !bn && j == L.H - 1 && j > 0 && L.N[j] <= 128;  // the last hidden layer also produces the scores
     if (fuse) {
       a.out_gamma = params + desc->off_gamma[L.H]; a.out_beta = params + desc->off_beta[L.H];
       a.out_W = params + desc->off_W[L.H]; a.out_bias = params + desc->off_b[L.H];
@@ -1865,7 +1892,7 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
     rc = launch_fwd_layer(a, fuse, st);
     if (rc) return rc;
   }
-  if (L.H > 1 && L.N[L.H - 1] <= 128) return ULTR_OK;  // scores came out of the fused epilogue
+  if (!bn && L.H > 1 && L.N[L.H - 1] <= 128) return ULTR_OK;  // scores came out of the fused epilogue
   OutArgs o{};
   const int j = L.H;
   if (j == 0) {
@@ -1877,6 +1904,13 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
   o.gamma = params + desc->off_gamma[j]; o.beta = params + desc->off_beta[j];
   o.W = params + desc->off_W[j]; o.bias = params + desc->off_b[j];
   o.K = L.K[j]; o.M = M; o.scores = scores;
+  if (bn) {
+    rc = bn_forward_input(o.x, o.ldx, o.docids, o.n_rows, L.K[j], round4(L.K[j]), M, desc->ln_eps, bn_train, o.gamma,
+                          o.beta, ws + L.cstat[j], ws + L.bn_part, ws + L.xhat_out, ws + L.bn_a, st);
+    if (rc) return rc;
+    o.x = ws + L.bn_a; o.ldx = round4(L.K[j]); o.docids = nullptr; o.n_rows = 0; o.row_stats = nullptr;
+    o.stat_out = nullptr; o.has_ln = 0;
+  }
   {
     ultr::ProfScope prof_("fwd_out_kernel", st);
     hipLaunchKernelGGL(fwd_out_kernel, dim3((unsigned)cdiv(M, 4)), dim3(kThreads), 0, st, o);
@@ -1924,7 +1958,43 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   ULTR_REQUIRE((desc->n_params & 3) == 0, ULTR_EINVAL, "ultr_dnn_backward: n_params=%lld must be a multiple of 4", desc->n_params);
   const int H = L.H;
   int cur = 0;  // which dz buffer holds the gradient wrt the current layer's output
-  {
+  const bool bn = L.bn;
+  ULTR_REQUIRE(desc->norm != ULTR_NORM_BATCH_EVAL, ULTR_EINVAL,
+               "ultr_dnn_backward: norm = batch (evaluation statistics) has no training pass");
+  if (bn) {
+    // Output layer under batch normalisation (bn_body.hpp): raw column sums of go and go * xhat give the layer's
+    // parameter gradients (one partial row for finalize) and the two column means of the normalisation's backward
+    // pass; dz of the last hidden layer follows elementwise.  No loss rides here: a parked one runs first.
+    if (g_pending_loss.kind != ULTR_RIDE_NONE) {
+      const PendingLoss pl = g_pending_loss;
+      g_pending_loss.kind = ULTR_RIDE_NONE;
+      rc = launch_loss_now(pl, st);
+      if (rc) return rc;
+    }
+    if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)desc->n_params, st) != hipSuccess) {
+      set_error("ultr_dnn_backward: hipMemsetAsync failed");
+      return ULTR_EHIP;
+    }
+    const float* gamma = params + desc->off_gamma[H];
+    const float* wout = params + desc->off_W[H];
+    BnSumArgs s{};
+    s.mode = 2; s.go = d_scores; s.xhat = ws + L.xhat_out; s.ldxh = round4(L.K[H]); s.K = L.K[H]; s.M = M;
+    s.part = ws + L.bn_part;
+    if ((rc = bn_launch_sum(s, st))) return rc;
+    BnFinishArgs f{};
+    f.mode = 3; f.part = ws + L.bn_part; f.K = L.K[H]; f.M = M; f.eps = desc->ln_eps; f.c12 = ws + L.c12;
+    f.gamma = gamma; f.beta = params + desc->off_beta[H]; f.w = wout; f.outrow = ws + L.outpart;
+    if ((rc = bn_launch_finish(f, st))) return rc;
+    if (H > 0) {
+      BnDxArgs x{nullptr, d_scores, wout, ws + L.xhat_out, ws + L.cstat[H], ws + L.c12, gamma, ws + L.act[H - 1],
+                 desc->activation, L.K[H], L.ldn[H - 1], M, ws + L.dz[cur]};
+      {
+        ProfScope prof_("bn_dx_kernel", st);
+        hipLaunchKernelGGL(bn_dx_kernel, dim3(bn_ew_blocks(M * L.ldn[H - 1])), dim3(256), 0, st, x);
+      }
+      if ((rc = check_launch("bn_dx_kernel"))) return rc;
+    }
+  } else {
     BwdOutArgs b{};
     OutArgs& o = b.f;
     if (H == 0) {
@@ -1991,6 +2061,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   else
     for (int j = 1; j < H; ++j)  // small GEMMs only: they leave most of the chip idle on their own
       if (2.0 * (double)M * L.K[j] * L.N[j] <= 0.25e9) pair_mask |= 1 << (j - 1);
+  if (bn) pair_mask = 0;  // the normalisation's column sums sit between dgrad and the row pass
   // A parked metric request (ultr_metrics_deferred) rides with layer 0's weight-gradient launch.  Measured at the
   // headline shape (wgrad alone -> with the rider): layer 0 (K136 N512) 12.4 -> 15.3 us, layer 2 (K256 N128) 9.3 -> 15.0,
   // layer 1 (K512 N256) 14.7 -> 24.1 against 14.4 us for a metric launch of its own: the heavier the carrier's operand
@@ -2000,7 +2071,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   // as a whole replays 8 us SLOWER (156 against 148 us) -- 160 workgroups of 16 rows stream every weight through
   // every CU and leave 96 CUs idle, and wgrad_2 loses its place beside dgrad_2.
   static const bool bchain_env = [] { const char* e = getenv("ULTR_BWD_CHAIN"); return e && e[0] == '1'; }();
-  bool use_chain = bchain_env && H >= 2 && H <= 3;
+  bool use_chain = bchain_env && H >= 2 && H <= 3 && !bn;
   if (use_chain) {
     BwdChainArgs c{};
     c.has_ln = has_ln; c.activation = desc->activation; c.H = H; c.M = M;
@@ -2102,6 +2173,25 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
         rc = check_launch("dgrad_kernel");
       }
       if (rc) return rc;
+      if (bn) {  // column means of gamma dh and gamma dh xhat, then dz_{j-1} elementwise, in place of the row pass
+        const float* gamma = params + desc->off_gamma[j];
+        BnSumArgs s{};
+        s.mode = 2; s.dh = ws + L.dz[nxt]; s.lddh = L.ldn[j - 1]; s.xhat = ws + L.xhat[j]; s.ldxh = round4(L.K[j]);
+        s.gamma = gamma; s.K = L.K[j]; s.M = M; s.part = ws + L.bn_part;
+        if ((rc = bn_launch_sum(s, st))) return rc;
+        BnFinishArgs bf{};
+        bf.mode = 2; bf.part = ws + L.bn_part; bf.K = L.K[j]; bf.M = M; bf.c12 = ws + L.c12;
+        if ((rc = bn_launch_finish(bf, st))) return rc;
+        BnDxArgs x{ws + L.dz[nxt], nullptr, nullptr, ws + L.xhat[j], ws + L.cstat[j], ws + L.c12, gamma, ws + L.act[j - 1],
+                   desc->activation, L.K[j], L.ldn[j - 1], M, ws + L.dz[nxt]};
+        {
+          ProfScope prof_("bn_dx_kernel", st);
+          hipLaunchKernelGGL(bn_dx_kernel, dim3(bn_ew_blocks(M * L.ldn[j - 1])), dim3(256), 0, st, x);
+        }
+        if ((rc = check_launch("bn_dx_kernel"))) return rc;
+        cur = nxt;
+        continue;
+      }
       RowpassArgs r{};
       r.dh = ws + L.dz[nxt]; r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
       r.a = ws + L.act[j - 1]; r.stat = ws + L.stat[j]; r.gamma = params + desc->off_gamma[j];
@@ -2132,8 +2222,10 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
     f.off_W[j] = desc->off_W[j]; f.off_b[j] = desc->off_b[j];
     f.off_gamma[j] = desc->off_gamma[j]; f.off_beta[j] = desc->off_beta[j];
   }
-  f.params = params; f.grads = grads; f.has_ln = has_ln;
-  f.outpart = ws + L.outpart; f.out_blocks = L.out_blocks; f.Kout = L.K[H];
+  // batch normalisation: xhat is column-normalised, the rest of the algebra (dW = gamma G + beta S, dgamma, dbeta) is
+  // LayerNorm's; the output layer left ONE partial row
+  f.params = params; f.grads = grads; f.has_ln = has_ln || bn;
+  f.outpart = ws + L.outpart; f.out_blocks = bn ? 1 : L.out_blocks; f.Kout = L.K[H];
   f.sumsq = sumsq;
   const unsigned fblocks = (unsigned)(start + (3 * L.K[H] + 1 + 63) / 64);
   if (g_pending_assemble.on && g_pending_assemble.nblocks <= 4096) {

@@ -1098,6 +1098,7 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   P.H = d->n_layers - 1;
   P.bf16 = d->compute_dtype == ULTR_DTYPE_BF16;
   if (P.H < 1 || L < 1 || L > 16 || B < 1) return P;
+  if (d->norm != ULTR_NORM_NONE && d->norm != ULTR_NORM_LAYER) return P;  // batch statistics couple the rows: per-layer plan
   P.nl = 16 / L;
   if (P.nl > 4) P.nl = 4;  // one 16-lane group per list in the loss lanes of a wave
   P.nwg = (int)cdiv(B, P.nl);

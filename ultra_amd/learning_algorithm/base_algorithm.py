@@ -192,10 +192,12 @@ class BaseAlgorithm(ABC):
                            stack(self.labels, torch.float32))
 
     # ---- reference helper API ------------------------------------------------------------------
-    def ranking_model(self, list_size, batch, out=None):
+    def ranking_model(self, list_size, batch, out=None, is_training=True):
         """Scores of the first ``list_size`` positions, position-major [list_size, B]
-        (base_algorithm.py:89-134: zero pad row, per-position gather, model.build, concat)."""
-        return self.model.forward_lists(batch.table, batch.table_stats, batch.n_rows, batch.docids[:list_size], out)
+        (base_algorithm.py:89-134: zero pad row, per-position gather, model.build, concat; is_training is the feed's
+        is_train placeholder, dla.py:103-117 -- it only matters under norm='batch')."""
+        return self.model.forward_lists(batch.table, batch.table_stats, batch.n_rows, batch.docids[:list_size], out,
+                                        is_training=is_training)
 
     # ---- buffers ---------------------------------------------------------------------------------
     N_LOCAL = 192                               # non-additive values (norms, pre-update EM state)
@@ -472,7 +474,7 @@ class BaseAlgorithm(ABC):
                   'out': torch.zeros(self.eval_plan.n_out, dtype=torch.float32, device=self.device),
                   'ws': dev_metrics.metrics_workspace(B, self.eval_plan, self.device)}
             self._eval_bufs[B] = eb
-        scores = self.ranking_model(Lx, batch, eb['scores'])
+        scores = self.ranking_model(Lx, batch, eb['scores'], is_training=False)
         u = torch.rand((B, Lx), dtype=torch.float32, device=self.device) if self.shuffle_ties else None
         dev_metrics.batch_metrics(self.eval_plan, scores, batch.labels, batch.docids, batch.n_rows, None, eb['out'],
                                   eb['ws'], u)

@@ -8,6 +8,7 @@ fp32-MFMA kernels of csrc/dnn.hip through ``ultr_dnn_forward`` / ``ultr_dnn_back
 Variables live in ONE flat fp32 device buffer (each tensor 64-float aligned; W_j rows padded to a
 multiple of 4 columns) so clip + Adagrad and the data-parallel all-reduce are single passes.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -62,8 +63,6 @@ class DNN(BaseRankingModel):
         if self.hparams.output_size != 1:
             raise NotImplementedError('output_size must be 1: scores are concatenated to [B, list] '
                                       '(base_algorithm.py:102)')
-        if self.hparams.norm == 'batch':
-            raise NotImplementedError("norm='batch' is not on the MI355X hot path (layer | none)")
         if len(self.hparams.hidden_layer_sizes) + 1 > _lib.ULTR_MAX_LAYERS:
             raise ValueError('at most %d layers' % _lib.ULTR_MAX_LAYERS)
         if self.act_func is None:
@@ -74,7 +73,9 @@ class DNN(BaseRankingModel):
         d.n_layers = len(shapes)
         d.in_features = feature_size
         d.activation = self.act_func
-        d.norm = _lib.NORM_LAYER if self.hparams.norm == 'layer' else _lib.NORM_NONE
+        # 'batch': keras BatchNormalization (DNN.py:70-84).  Training passes use the batch statistics (NORM_BATCH); the
+        # evaluation pass (is_training=False) the moving statistics, which the reference never updates (desc_eval)
+        d.norm = {'layer': _lib.NORM_LAYER, 'batch': _lib.NORM_BATCH}.get(self.hparams.norm, _lib.NORM_NONE)
         d.ln_eps = LN_EPS
         dtype = getattr(self.hparams, 'compute_dtype', 'f32')  # subclasses with their own hparams (Linear) have none
         if dtype not in ('f32', 'bf16'):
@@ -97,6 +98,11 @@ class DNN(BaseRankingModel):
         # (regression-EM's sigmoid_prob_b) so one clip + Adagrad pass covers every trainable variable
         self.n_total = off + 64
         self.desc = d
+        self.desc_eval = d
+        if d.norm == _lib.NORM_BATCH:
+            self.desc_eval = _lib.UltrDnnDesc()
+            ctypes.memmove(ctypes.byref(self.desc_eval), ctypes.byref(d), ctypes.sizeof(d))
+            self.desc_eval.norm = _lib.NORM_BATCH_EVAL
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(int(seed) if seed is not None else torch.seed() % (1 << 31))
         host = np.zeros(self.n_total, dtype=np.float32)
@@ -134,7 +140,7 @@ class DNN(BaseRankingModel):
             self.model_parameters['ranking_model/dnn_W_%d:0' % j] = self.params[o:o + ln].view(ent['K'], ent['ldw'])[:, :ent['N']]
             o, ln = ent['b']
             self.model_parameters['ranking_model/dnn_b_%d:0' % j] = self.params[o:o + ln]
-            if self.desc.norm == _lib.NORM_LAYER:
+            if self.desc.norm in (_lib.NORM_LAYER, _lib.NORM_BATCH):  # both layers are named layer_norm_%d (DNN.py:73-74)
                 o, ln = ent['gamma']
                 self.model_parameters['ranking_model/layer_norm_%d/gamma:0' % j] = self.params[o:o + ln]
                 o, ln = ent['beta']
@@ -172,14 +178,15 @@ class DNN(BaseRankingModel):
             self._ws[M] = ws
         return ws
 
-    def forward_lists(self, table, table_stats, n_rows, docids_lb, out=None):
-        """Scores [L, B] (position-major) of the docs ``table[docids_lb]``; id == n_rows is the pad row."""
+    def forward_lists(self, table, table_stats, n_rows, docids_lb, out=None, is_training=True):
+        """Scores [L, B] (position-major) of the docs ``table[docids_lb]``; id == n_rows is the pad row.
+        ``is_training`` only matters under norm='batch' (batch statistics against the moving ones, DNN.py:82-84)."""
         L, B = docids_lb.shape
         M = L * B
         scores = out if out is not None else torch.empty((L, B), dtype=torch.float32, device=self.device)
         ws = self._workspace(M)
         _lib.check(_lib.lib().ultr_dnn_forward(
-            self.desc, _lib.ptr(self.params), _lib.ptr(table), _lib.ptr(table_stats), int(n_rows), int(table.stride(0)),
+            self.desc if is_training else self.desc_eval, _lib.ptr(self.params), _lib.ptr(table), _lib.ptr(table_stats), int(n_rows), int(table.stride(0)),
             _lib.ptr(docids_lb), M, _lib.ptr(ws), _lib.ptr(scores), _lib.current_stream()), 'ultr_dnn_forward')
         self._last = (table, table_stats, int(n_rows), docids_lb, M, ws)
         return scores
@@ -249,7 +256,7 @@ class DNN(BaseRankingModel):
         table[:, :F] = torch.cat([x.to(torch.float32) for x in input_list], dim=0)
         stats = feature_row_stats(table, F)
         docids = torch.arange(L * B, dtype=torch.int32, device=self.device).view(L, B)
-        scores = self.forward_lists(table, stats, L * B, docids)
+        scores = self.forward_lists(table, stats, L * B, docids, is_training=bool(is_training))
         return [scores[l].view(B, 1) for l in range(L)]
 
 
