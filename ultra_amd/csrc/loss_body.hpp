@@ -117,18 +117,26 @@ __device__ __forceinline__ DlaTower dla_tower(const float* __restrict__ prop_par
 // ds = un-normalised d rank_loss / d score.  The 16 lanes of a group hold the 16 ranks of one list.  Shared by
 // the loss kernel and by the backward pass's first launch, which evaluates ds in place of reading d_scores when
 // it carries the loss (ultr_loss_dla_deferred): no implicit contraction, so both produce the same bits.
-struct DlaLane { float m, ex, se, wl, S, lse, ds; };
+// The kernel is bound by its arithmetic, not its bytes (measured: ~200 instructions per wave and 4 lists), so the
+// softmax runs on the hardware exponential / logarithm / reciprocal (v_exp_f32, v_log_f32, v_rcp_f32: 1 ulp each on
+// arguments that are <= 0 after the max is taken off -- far inside the 1e-5 parity bound) and evaluates ONE exponential
+// per element: softmax_l = ex_l / se serves the gradient, the probabilities and the relevance weights.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+struct DlaLane { float m, ex, se, wl, S, lse, ds, sm; };
 __device__ __forceinline__ DlaLane dla_lane(float o, float c, float pw, bool live, int loss_func) {
 #pragma clang fp contract(off)
   DlaLane v;
   v.m = group_max<16>(live ? o : -INFINITY);
-  v.ex = live ? expf(o - v.m) : 0.f;
+  v.ex = live ? fast_exp(o - v.m) : 0.f;
   v.se = group_sum<16>(v.ex);
   v.wl = live ? (c + 0.0000001f) * pw : 0.f;
   v.S = group_sum<16>(v.wl);
-  v.lse = v.m + logf(v.se);
+  v.lse = v.m + fast_log(v.se);
+  v.sm = v.ex * fast_rcp(v.se);  // softmax(o)_l
   if (loss_func == ULTR_LOSS_SOFTMAX) {
-    v.ds = expf(o - v.lse) * v.S - v.wl;
+    v.ds = v.sm * v.S - v.wl;
   } else {
     v.ds = (sigmoidf_(o) - fminf(c, 1.f)) * pw;
   }
@@ -165,9 +173,9 @@ __device__ __forceinline__ void dla_loss_small_body(const DlaArgs& a, unsigned i
     const DlaLane v = dla_lane(o, c, pw, live, loss_func);
     // the list's relevance weights
     const float mean = group_sum<16>(live ? o : 0.f) / (float)L;
-    const float pl = prob_kind == ULTR_PROB_SOFTMAX ? v.ex / v.se : sigmoidf_(o - mean);
+    const float pl = prob_kind == ULTR_PROB_SOFTMAX ? v.sm : sigmoidf_(o - mean);
     const float p0 = group_sum<16>(r == 0 ? pl : 0.f);
-    const float rw = live ? clip_w(p0 / pl, max_pw) : 0.f;  // relevance weights (dla.py:159-160)
+    const float rw = live ? clip_w(p0 * fast_rcp(pl), max_pw) : 0.f;  // relevance weights (dla.py:159-160)
     const float cl = fminf(fmaxf(c, 0.f), 1.f);
     const float lw = group_sum<16>(live ? pw * cl : 0.f);
     rw_sum += rw;
