@@ -60,6 +60,10 @@ struct Layout {
   int maxld;
   // batch normalisation only (bn_body.hpp): column statistics per layer, the scratch of the column sums, the
   // normalised-and-scaled input `a` of the layer being run, xhat of the output layer's input
+  // large batches (wgall): every layer's weight gradient in ONE launch of the LDS-DMA ring kernel (fused.hip), after
+  // the dgrad chain -- so each layer's dz keeps a buffer of its own, and all layers share one row split
+  bool wgall;
+  long long dzl[ULTR_MAX_LAYERS];      // [M][ldn_j]
   bool bn;
   long long cstat[ULTR_MAX_LAYERS + 1];  // [K_j][2] (mean, rstd)
   long long c12, bn_part, bn_a, xhat_out;
@@ -93,7 +97,23 @@ static Layout make_layout(const UltrDnnDesc* d, long long M) {
   for (int j = 0; j < L.H; ++j) {
     L.xhat[j] = take(M * round4(L.K[j]));
   }
+  // Measured at M = 40960 (MSLR shape): the three register-streaming wgrad launches 140 + 106 + 42 us (54-77 TFLOP/s),
+  // wgrad_all_kernel 199 us (96 TFLOP/s).  Needs whole 32-row chunks (no row masks in its ring).
+  L.wgall = M >= 16384 && (M & 31) == 0 && L.H >= 1 && d->norm != ULTR_NORM_BATCH && d->norm != ULTR_NORM_BATCH_EVAL;
+  long long all_tiles = 0;
+  for (int j = 0; j < L.H; ++j) all_tiles += cdiv(L.K[j], 64) * cdiv(L.N[j], 64);
   for (int j = 0; j < L.H; ++j) {
+    if (L.wgall) {  // two workgroups per CU over all layers together, one row split for all
+      long long ns = 512 / all_tiles > 1 ? 512 / all_tiles : 1;
+      if (ns > cdiv(M, 64)) ns = cdiv(M, 64);
+      const long long rps = cdiv(cdiv(M, ns), 32) * 32;
+      L.rows_per_split[j] = (int)rps;
+      L.nsplit[j] = (int)cdiv(M, rps);
+      L.gslab[j] = take((long long)L.nsplit[j] * L.K[j] * L.ldn[j]);
+      L.sslab[j] = take((long long)L.nsplit[j] * L.ldn[j]);
+      L.dzl[j] = take(M * L.ldn[j]);
+      continue;
+    }
     const long long tiles = cdiv(L.K[j], 64) * cdiv(L.N[j], 64);
     // Whole rounds of workgroups: at most one per CU (256) -- 24 tiles x 11 slabs = 264 workgroups would run a
     // second round for 8 of them and take twice as long -- or, when every slab still spans 512 rows, three per CU
@@ -1959,6 +1979,8 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   const int H = L.H;
   int cur = 0;  // which dz buffer holds the gradient wrt the current layer's output
   const bool bn = L.bn;
+  // where the gradient wrt layer j's output lives: its own buffer (wgall) or rotating slot `slot`
+  auto dz_of = [&](int j, int slot) { return L.wgall ? ws + L.dzl[j] : ws + L.dz[slot]; };
   ULTR_REQUIRE(desc->norm != ULTR_NORM_BATCH_EVAL, ULTR_EINVAL,
                "ultr_dnn_backward: norm = batch (evaluation statistics) has no training pass");
   if (bn) {
@@ -2008,7 +2030,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
     o.W = params + desc->off_W[H]; o.bias = params + desc->off_b[H];
     o.K = L.K[H]; o.M = M;
     b.d_scores = d_scores; b.activation = desc->activation; b.has_prev = H > 0;
-    b.dz = ws + L.dz[cur]; b.lddz = H > 0 ? L.ldn[H - 1] : 0;
+    b.dz = H > 0 ? dz_of(H - 1, cur) : ws + L.dz[cur]; b.lddz = H > 0 ? L.ldn[H - 1] : 0;
     b.rows_per_block = L.out_rows_per_block; b.partials = ws + L.outpart;
     b.zero = grads; b.zero_n4 = desc->n_params / 4;  // cleared by the first kernel of the pass, filled by the last
     const size_t smem = sizeof(float) * 4 * (3 * (size_t)L.K[H] + 1);
@@ -2062,6 +2084,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
     for (int j = 1; j < H; ++j)  // small GEMMs only: they leave most of the chip idle on their own
       if (2.0 * (double)M * L.K[j] * L.N[j] <= 0.25e9) pair_mask |= 1 << (j - 1);
   if (bn) pair_mask = 0;  // the normalisation's column sums sit between dgrad and the row pass
+  if (L.wgall) pair_mask = 0;  // the weight gradients come after the dgrad chain, in one launch
   // A parked metric request (ultr_metrics_deferred) rides with layer 0's weight-gradient launch.  Measured at the
   // headline shape (wgrad alone -> with the rider): layer 0 (K136 N512) 12.4 -> 15.3 us, layer 2 (K256 N128) 9.3 -> 15.0,
   // layer 1 (K512 N256) 14.7 -> 24.1 against 14.4 us for a metric launch of its own: the heavier the carrier's operand
@@ -2071,7 +2094,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   // as a whole replays 8 us SLOWER (156 against 148 us) -- 160 workgroups of 16 rows stream every weight through
   // every CU and leave 96 CUs idle, and wgrad_2 loses its place beside dgrad_2.
   static const bool bchain_env = [] { const char* e = getenv("ULTR_BWD_CHAIN"); return e && e[0] == '1'; }();
-  bool use_chain = bchain_env && H >= 2 && H <= 3 && !bn;
+  bool use_chain = bchain_env && H >= 2 && H <= 3 && !bn && !L.wgall;
   if (use_chain) {
     BwdChainArgs c{};
     c.has_ln = has_ln; c.activation = desc->activation; c.H = H; c.M = M;
@@ -2108,7 +2131,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   }
   int carrier = -1;
   if (g_pending_metrics.on) {
-    if (H >= 1 && g_pending_metrics.nblocks <= 64) carrier = 0;  // a bigger request is no rider: a launch of its own
+    if (H >= 1 && g_pending_metrics.nblocks <= 64 && !L.wgall) carrier = 0;  // a bigger request is no rider: a launch of its own
     static const int carrier_env = [] { const char* e = getenv("ULTR_RIDE_CARRIER"); return e ? atoi(e) : -1; }();  // experiments
     if (carrier_env >= 0 && carrier_env < H && !pair_mask) carrier = carrier_env;
     if (carrier < 0) {
@@ -2117,15 +2140,18 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
       if (rc) return rc;
     }
   }
+  WgradArgs wg_all[ULTR_MAX_LAYERS];
   for (int j = H - 1; j >= 0; --j) {
     WgradArgs g{};
     g.xhat = ws + L.xhat[j]; g.ldx = round4(L.K[j]);
-    g.dz = ws + L.dz[cur]; g.ldn = L.ldn[j]; g.N = L.N[j];
+    g.dz = dz_of(j, cur); g.ldn = L.ldn[j]; g.N = L.N[j];
     g.K = L.K[j]; g.M = M; g.rows_per_split = L.rows_per_split[j];
     g.gslab = ws + L.gslab[j]; g.sslab = ws + L.sslab[j];
     const dim3 ggrid((unsigned)L.nsplit[j], (unsigned)cdiv(L.K[j], 64), (unsigned)cdiv(L.ldn[j], 64));
     const bool pair = !use_chain && j > 0 && j != carrier && ((pair_mask >> (j - 1)) & 1);
-    if (j == carrier) {
+    if (L.wgall) {
+      wg_all[j] = g;  // launched together after the dgrad chain
+    } else if (j == carrier) {
       WgradRiderArgs wr{};
       wr.g = g; wr.g_gx = (int)ggrid.x; wr.g_gy = (int)ggrid.y; wr.g_gz = (int)ggrid.z;
       wr.m = g_pending_metrics.a; wr.m_blocks = (int)g_pending_metrics.nblocks; wr.m_pad = (wr.m_blocks + 7) & ~7;
@@ -2151,10 +2177,10 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
     } else if (j > 0) {
       const int nxt = (cur + 1) % 3;
       DgradArgs d{};
-      d.dz = ws + L.dz[cur]; d.ldn = L.ldn[j]; d.N = L.N[j];
+      d.dz = dz_of(j, cur); d.ldn = L.ldn[j]; d.N = L.N[j];
       d.W = params + desc->off_W[j];
       d.K = L.K[j]; d.ldk = L.ldn[j - 1]; d.M = M;
-      d.dh = ws + L.dz[nxt];
+      d.dh = dz_of(j - 1, nxt);
       const dim3 dgrid((unsigned)cdiv(M, 32), (unsigned)cdiv(L.ldn[j - 1], 128));
       if (pair) {
         BwdPairArgs bp{g, d, (int)dgrid.x, (int)dgrid.y, (int)ggrid.x, (int)ggrid.y, (int)ggrid.z};
@@ -2193,7 +2219,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
         continue;
       }
       RowpassArgs r{};
-      r.dh = ws + L.dz[nxt]; r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
+      r.dh = dz_of(j - 1, nxt); r.ldk = L.ldn[j - 1]; r.K = L.K[j]; r.M = M;
       r.a = ws + L.act[j - 1]; r.stat = ws + L.stat[j]; r.gamma = params + desc->off_gamma[j];
       r.has_ln = has_ln; r.activation = desc->activation;
       {
@@ -2207,6 +2233,10 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
       if (rc) return rc;
       cur = nxt;
     }
+  }
+  if (L.wgall) {
+    rc = launch_wgrad_all(H, wg_all, L.nsplit[0], false, st);
+    if (rc) return rc;
   }
   FinalizeArgs f{};
   f.H = H;

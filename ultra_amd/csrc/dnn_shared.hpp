@@ -62,6 +62,11 @@ struct WgradArgs {
   float* sslab;            // [nsplit][ldn]
 };
 
+// Every layer's weight-gradient GEMM in one launch of the LDS-DMA ring kernel (fused.hip): layers[j] for j < n_layers,
+// all with the same rows_per_split / nsplit; operand rows must come in whole 32-row chunks (M % 32 == 0 or zero rows
+// behind M).  bf16: operands rounded to bf16 on their way to the registers.
+int launch_wgrad_all(int n_layers, const WgradArgs* layers, int nsplit, bool bf16, hipStream_t st);
+
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, int bx, int by, int bz) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int wr = w >> 1, wc = w & 1;

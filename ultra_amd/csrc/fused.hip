@@ -1158,6 +1158,37 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
 
 }  // namespace ultr
 
+namespace ultr {
+int launch_wgrad_all(int n_layers, const WgradArgs* layers, int nsplit, bool bf16, hipStream_t st) {
+  WgradAllArgs g{};
+  g.n_layers = n_layers; g.nsplit = nsplit; g.bf16 = bf16 ? 1 : 0;
+  int start = 0;
+  long long pw = 0;
+  for (int j = 0; j < n_layers; ++j) {
+    g.g[j] = layers[j];
+    g.start[j] = start; g.gy[j] = (int)cdiv(layers[j].K, 64);
+    start += nsplit * g.gy[j] * (int)cdiv(layers[j].ldn, 64);
+    pw += (long long)layers[j].K * layers[j].N;
+  }
+  g.start[n_layers] = start;
+  static bool wg_attr = false;
+  if (!wg_attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kWgRingBytes) != hipSuccess) {
+      set_error("wgrad_all_kernel: cannot raise the dynamic LDS limit");
+      return ULTR_EHIP;
+    }
+    wg_attr = true;
+  }
+  {
+    ProfScope prof_(g_profile_on ? profile_intern(bf16 ? "wgrad_all_kernel_bf16/P%lld" : "wgrad_all_kernel/P%lld", pw)
+                                 : "wgrad_all_kernel", st);
+    hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)start), dim3(kThreads), kWgRingBytes, st, g);
+  }
+  return check_launch("wgrad_all_kernel");
+}
+}  // namespace ultr
+
 using namespace ultr;
 
 #ifdef ULTR_STAMPS
@@ -1328,36 +1359,17 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   else rc = launch_chain<ULTR_RIDE_PD>(a, P.nwg, P.smem_bytes, fast, st);
   if (rc) return rc;
 
-  // ---- every weight-gradient GEMM + loss statistics + in-step metrics
+  // ---- every weight-gradient GEMM
   {
-    WgradAllArgs g{};
-    g.n_layers = H; g.nsplit = P.nsplit; g.bf16 = P.bf16 ? 1 : 0;
-    int start = 0;
+    WgradArgs layers[ULTR_MAX_LAYERS];
     for (int j = 0; j < H; ++j) {
-      WgradArgs& q = g.g[j];
+      WgradArgs& q = layers[j];
       q.xhat = ws + P.xhat[j]; q.ldx = round4(P.K[j]);
       q.dz = ws + P.dz[j]; q.ldn = P.ldn[j]; q.N = P.N[j];
       q.K = P.K[j]; q.M = M; q.rows_per_split = P.rows_per_split;
       q.gslab = ws + P.gslab[j]; q.sslab = ws + P.sslab[j];
-      g.start[j] = start; g.gy[j] = (int)cdiv(P.K[j], 64);
-      start += P.nsplit * g.gy[j] * (int)cdiv(P.ldn[j], 64);
     }
-    g.start[H] = start;
-    static bool wg_attr = false;
-    if (!wg_attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kWgRingBytes) != hipSuccess) {
-        set_error("ultr_dnn_train_fused: cannot raise the dynamic LDS limit");
-        return ULTR_EHIP;
-      }
-      wg_attr = true;
-    }
-    {
-      ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern(P.bf16 ? "wgrad_all_kernel_bf16/P%lld" : "wgrad_all_kernel/P%lld", [&] {
-        long long s = 0; for (int j = 0; j < H; ++j) s += (long long)P.K[j] * P.N[j]; return s; }()) : "wgrad_all_kernel", st);
-      hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)start), dim3(kThreads), kWgRingBytes, st, g);
-    }
-    rc = check_launch("wgrad_all_kernel");
+    rc = launch_wgrad_all(H, layers, P.nsplit, P.bf16, st);
     if (rc) return rc;
   }
 
