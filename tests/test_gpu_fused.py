@@ -30,13 +30,20 @@ CASES = [
     ('RegressionEM', '', 'hidden_layer_sizes=[48]', 17, 3, 100),
     ('PairDebias', '', 'hidden_layer_sizes=[256, 128]', 60, 10, 128),
     ('PairDebias', '', 'hidden_layer_sizes=[64, 32]', 24, 8, 31),
+    # edges: one-document lists (four lists per workgroup, one row each), two-document lists, a single list, one hidden
+    # layer narrower than an MFMA unit, a hidden layer close to what LDS can hold
+    ('DLA', '', 'hidden_layer_sizes=[32, 16]', 12, 1, 37),
+    ('IPWrank', 'propensity_estimator_json=%s' % IPW_JSON, 'hidden_layer_sizes=[32]', 12, 2, 9),
+    ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 10, 1),
+    ('RegressionEM', '', 'hidden_layer_sizes=[8]', 5, 6, 20),
+    ('DLA', '', 'hidden_layer_sizes=[768, 16]', 40, 10, 24),
 ]
 
 
 @pytest.mark.parametrize('algo,hp,mhp,F,L,B', CASES)
 def test_fused_step_equals_the_per_launch_plan(algo, hp, mhp, F, L, B):
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
-    data = SyntheticData(300, L, F, seed=11, pad_frac=0.2)
+    data = SyntheticData(300, L, F, seed=11, pad_frac=0.2 if L > 2 else 0.0)
     click = CASCADE if algo == 'PairDebias' else PBM
     exp = settings(algo, hp, mhp, Lmax=L, cutoff=L, feed_hparams='click_model_json=%s' % click)
     m1, feed = make(algo, data, exp, B)
