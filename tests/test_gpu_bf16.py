@@ -99,3 +99,24 @@ def test_bf16_weight_copies_follow_the_parameters():
         m1.step(None, fd, False)
         m2.step(None, fd, False)
         assert torch.equal(m1.model.params, m2.model.params), step
+
+
+def test_bf16_step_stays_fused_beyond_the_fp32_row_limit():
+    """The fp32 fused step hands over to the per-launch plan above 8192 rows; the bf16 step does not (it is faster at
+    every size).  1024 lists of 10: still the fused path, still inside the stated bound."""
+    from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
+    B, L, F = 1024, 10, 136
+    data = SyntheticData(2000, L, F, seed=9, pad_frac=0.1)
+    out = {}
+    for dt in ('f32', 'bf16'):
+        exp = settings('DLA', '', 'hidden_layer_sizes=[512, 256, 128],compute_dtype=%s' % dt, Lmax=L, cutoff=L)
+        m, feed = make('DLA', data, exp, B)
+        fd, _ = feed.get_batch(data, check_validation=True)
+        m.step_local(fd)
+        torch.cuda.synchronize()
+        out[dt] = (m._train_bufs['fused'], m._train_bufs['scores'].cpu().numpy(),
+                   (m._train_bufs['grads'] / m._train_bufs['stats'][1]).cpu().numpy())
+        m.step_apply()
+    assert out['bf16'][0] and not out['f32'][0]
+    assert relerr(out['bf16'][1], out['f32'][1]) < 1e-2
+    assert relerr(out['bf16'][2], out['f32'][2]) < 2e-2

@@ -13,3 +13,4 @@ run c3_yahoo_b4096 --config yahoo --batch 4096
 run c2_mslr10k_b256_bf16 --config mslr10k --batch 256 --dtype bf16
 run c3_yahoo_b256_bf16 --config yahoo --batch 256 --dtype bf16
 run c4_istella_b256_bf16 --config istella --batch 256 --dtype bf16
+run c5_mslr30k_b4096_bf16 --config mslr30k --batch 4096 --dtype bf16

@@ -391,7 +391,10 @@ class BaseAlgorithm(ABC):
 
     def _fused_ok(self, batch):
         """Short lists run forward + loss gradient + backward as ONE call (ultr_dnn_train_fused)."""
-        return self.fused_step and self._loss_rides() and batch.B * batch.L <= self.fused_max_rows and \
+        # (the bf16 step streams half the bytes and spends next to nothing on MFMA: it stays ahead of the fp32 per-launch
+        # plan at every size -- 613 against 810 us at 40960 rows -- so only the fp32 step hands over)
+        bf16 = self.model.desc.compute_dtype == _lib.DTYPE_BF16
+        return self.fused_step and self._loss_rides() and (bf16 or batch.B * batch.L <= self.fused_max_rows) and \
             self.model.fused_supported(batch.B, batch.L)
 
     def _step_local_fused(self, tb, batch):
