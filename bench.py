@@ -105,7 +105,8 @@ def build_world(cfg, args, device):
            'learning_algorithm': 'ultra_amd.learning_algorithm.' + cfg['algo'],
            'learning_algorithm_hparams': args.algo_hparams,
            'metrics': ['mrr', 'ndcg'], 'metrics_topn': [3, 5, 10],
-           'max_candidate_num': cfg['L'], 'selection_bias_cutoff': cfg['L'], 'seed': 1}
+           'max_candidate_num': cfg['L'], 'selection_bias_cutoff': cfg['L'], 'seed': 1,
+           'metric_shuffle_ties': bool(args.shuffle_ties)}
     if cfg['algo'] == 'IPWrank':
         exp['learning_algorithm_hparams'] = 'propensity_estimator_json=%s' % os.path.join(
             GOLDEN, 'randomized_pbm_0.1_1.0_4_1.0.json')
@@ -216,6 +217,8 @@ def main():
                     help='f32: the parity path (headline).  bf16: the opt-in fast path -- forward and dgrad GEMMs of the '
                          'hidden layers on bf16 MFMA with fp32 accumulation, the rest fp32 (bound: DESIGN.md section 3); '
                          'its roofline is priced against the bf16 matrix peak')
+    ap.add_argument('--shuffle_ties', type=int, default=1,
+                    help='1 (the reference default): the in-step metrics break score ties with fresh uniforms; 0: index order')
     ap.add_argument('--cpu_seconds', type=float, default=12.0)
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')

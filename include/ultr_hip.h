@@ -397,6 +397,20 @@ int ultr_metrics(const float* scores, const float* labels, const int* docids, in
 int ultr_metrics_deferred(const float* scores, const float* labels, const int* docids, int n_rows,
                  const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
                  int n_topn, int metric_mask, float max_label, float* out, float* ws, void* stream);
+/* ultr_metrics / ultr_metrics_deferred with the tie-break uniforms drawn inside the kernel instead of supplied:
+ * sort_by_scores shuffles ties with fresh uniforms on every call (metric_utils.py:49-86, shuffle_ties=True, the default
+ * of every metric in metrics.py).  Philox4x32-10 keyed by tie_seed (!= 0), counter (tie_slot_base + list, 'TIE',
+ * rank / 4, tie_step + *tie_ctr); tie_ctr (device, may be NULL) is bumped by the launch's last workgroup, so a captured
+ * graph draws new uniforms on every replay; tie_slot_base = rank * B makes N data-parallel ranks draw what one rank with
+ * the whole batch would.  The uniforms only matter where scores tie exactly (pad documents, constant initialisers). */
+int ultr_metrics_ties(const float* scores, const float* labels, const int* docids, int n_rows,
+                      const float* list_weights, int B, int Lx, const int* topn_h, int n_topn, int metric_mask,
+                      float max_label, unsigned long long tie_seed, unsigned int tie_step, unsigned int* tie_ctr,
+                      unsigned int tie_slot_base, float* out, float* ws, void* stream);
+int ultr_metrics_ties_deferred(const float* scores, const float* labels, const int* docids, int n_rows,
+                               const float* list_weights, int B, int Lx, const int* topn_h, int n_topn, int metric_mask,
+                               float max_label, unsigned long long tie_seed, unsigned int tie_step, unsigned int* tie_ctr,
+                               unsigned int tie_slot_base, float* out, float* ws, void* stream);
 int ultr_metrics_flush(void* stream);
 /* Drop a parked request without running it (the scores it describes never came to be); returns 1 if there was one. */
 int ultr_metrics_cancel(void);

@@ -180,6 +180,20 @@ def philox_uniforms(seed, step, slot, attempt, n):
     return u53(words[0:2 * n:2], words[1:2 * n:2])
 
 
+def tie_uniforms(seed, step, slot_base, n_lists, list_len):
+    """The metric kernels' in-kernel tie-break uniforms (new; stands in for the fresh tf.random_uniform of
+    metric_utils.py:76-81): list b, rank r draws word r % 4 of Philox block counter (slot_base + b, 'TIE', r // 4, step)
+    under key ``seed``, as a 24-bit float32 in [0, 1).  -> float32 [n_lists, list_len]."""
+    nblk = (list_len + 3) // 4
+    ctr = np.zeros((n_lists, nblk, 4), dtype=np.uint32)
+    ctr[:, :, 0] = (slot_base + np.arange(n_lists, dtype=np.uint64))[:, None] & 0xFFFFFFFF
+    ctr[:, :, 1] = 0x544945
+    ctr[:, :, 2] = np.arange(nblk)[None, :]
+    ctr[:, :, 3] = step
+    words = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(n_lists, nblk * 4)[:, :list_len]
+    return ((words >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
 def get_batch_slots(initial_list, labels, rank_list_size, batch_size, model_name, click_prob,
                     exam_prob, seed, step, slot_base=0, max_attempts=100, check_validation=True, extra=None):
     """Per-slot rejection sampling: slot s retries with attempt t = 0,1,.. on its own stream.

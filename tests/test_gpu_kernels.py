@@ -918,3 +918,33 @@ def test_online_kernels_short_and_long_list_layouts_agree(L, model_file, stochas
         assert np.array_equal(a, b), name
     shown = np.minimum(lens, Ls) > 0
     assert (outs[0][1][:Ls].sum(0)[shown] >= 1).all()
+
+
+@pytest.mark.parametrize('B,Lx', [(200, 10), (40000, 10), (25, 40)])  # 16 lanes per list, one lane per list, LDS bitonic sort
+def test_metrics_kernel_draws_its_own_tie_break_uniforms(L, B, Lx):
+    """ultr_metrics_ties: ties between equal scores are broken by Philox uniforms drawn inside the kernel (the reference
+    draws fresh tf.random_uniform values per call, metric_utils.py:76-81); the oracle regenerates the same uniforms, and the
+    device counter makes the second call draw new ones."""
+    from ultra_amd.utils import metrics as M
+    rng = np.random.RandomState(B + Lx)
+    labels = rng.choice(3, size=(B, Lx), p=[0.6, 0.25, 0.15]).astype(np.float64)
+    scores = np.round(rng.normal(size=(B, Lx)), 0).astype(np.float32)         # integers: ties everywhere
+    topn = [1, 3, 5, 10]
+    plan = M.MetricPlan(['mrr', 'ndcg', 'err'], topn)
+    out = torch.zeros(plan.n_out, dtype=torch.float32, device='cuda')
+    ws = M.metrics_workspace(B, plan, 'cuda')
+    ctr = torch.zeros(1, dtype=torch.int32, device='cuda')
+    seed, slot_base = 0x1234567887654321, 1000
+    s_dev, l_dev = dev(scores.T), dev(labels.T, torch.float32)
+    seen = []
+    for call in range(2):
+        M.batch_metrics(plan, s_dev, l_dev, None, 0, None, out, ws, None, max_label=2.0, ties=(seed, 7, ctr, slot_base))
+        got = out.cpu().numpy().astype(np.float64)
+        assert int(ctr.item()) == call + 1
+        u = O.tie_uniforms(seed, 7 + call, slot_base, B, Lx)
+        for i, k in enumerate(topn):
+            assert abs(got[plan.slot('ndcg', i, False)] - O.ndcg(labels, scores.astype(np.float64), None, k, u, u)) < 2e-6
+            assert abs(got[plan.slot('err', i, False)] - O.err(labels, scores.astype(np.float64), 2.0, None, k, u)) < 2e-6
+            assert abs(got[plan.slot('mrr', i, False)] - O.mrr(labels, scores.astype(np.float64), None, u)) < 2e-6
+        seen.append(got.copy())
+    assert not np.array_equal(seen[0], seen[1])                               # fresh draws on the second call

@@ -102,6 +102,10 @@ SIGNATURES = {
     'ultr_metrics_static_max_floats': (_LL, []),
     'ultr_metrics_static': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P]),
     'ultr_metrics_deferred': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
+    'ultr_metrics_ties': (_I, [_P, _P, _P, _I, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F,
+                               ctypes.c_ulonglong, ctypes.c_uint, _P, ctypes.c_uint, _P, _P, _P]),
+    'ultr_metrics_ties_deferred': (_I, [_P, _P, _P, _I, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F,
+                                        ctypes.c_ulonglong, ctypes.c_uint, _P, ctypes.c_uint, _P, _P, _P]),
     'ultr_metrics_flush': (_I, [_P]),
     'ultr_metrics_cancel': (_I, []),
     'ultr_host_device_pointer': (_I, [_P, ctypes.POINTER(ctypes.c_void_p)]),

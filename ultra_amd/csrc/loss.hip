@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
       } else {
         if ((l & 3) == 0) rnd = philox4x32_10(slot_base + (uint32_t)b, 0x52454Du, (uint32_t)(l >> 2), step,
                                              (uint32_t)seed, (uint32_t)(seed >> 32));
-        u = u24(rnd.v[l & 3]);
+        u = u24(philox_word(rnd, l));
       }
       y = ceilf(p_r1 - u);  // get_bernoulli_sample (:39)
       y = y > 0.f ? y : 0.f;  // ceil(-0.x) = -0 -> 0

@@ -340,7 +340,7 @@ __device__ __forceinline__ RemElem rem_elem_v(const RemArgs& a, float bias, floa
   } else {
     const Philox4 rnd = philox4x32_10(a.slot_base + (uint32_t)b, 0x52454Du, (uint32_t)(r >> 2), step, (uint32_t)a.seed,
                                       (uint32_t)(a.seed >> 32));
-    u = u24(rnd.v[r & 3]);
+    u = u24(philox_word(rnd, r));
   }
   v.y = ceilf(p_r1 - u);      // get_bernoulli_sample (:39)
   v.y = v.y > 0.f ? v.y : 0.f;  // ceil(-0.x) = -0 -> 0

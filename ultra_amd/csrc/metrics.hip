@@ -56,7 +56,9 @@ __device__ __forceinline__ void bitonic_sort_tile(const SortTile& t, int P, int 
 __device__ __forceinline__ void load_tile(const SortTile& t, const float* __restrict__ scores,
                                           const float* __restrict__ labels, const int* __restrict__ docids,
                                           int n_rows, const float* __restrict__ u_pred, int B, int Lx, int P, int E,
-                                          int LPB) {
+                                          int LPB, const MetricsArgs* ties = nullptr) {
+  const bool draw_ties = ties && !u_pred && ties->tie_seed != 0ull;
+  const unsigned int t_step = draw_ties ? tie_step_of(*ties) : 0u;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     const int li = e & (P - 1);
     const int b = blockIdx.x * LPB + e / P;
@@ -67,7 +69,7 @@ __device__ __forceinline__ void load_tile(const SortTile& t, const float* __rest
       s = scores[g];
       if (docids && docids[g] == n_rows) s = kPaddingScore;
       lb = labels ? labels[g] : 0.f;
-      uu = u_pred ? u_pred[(long long)b * Lx + li] : 0.f;
+      uu = u_pred ? u_pred[(long long)b * Lx + li] : draw_ties ? tie_uniform(*ties, t_step, b, li) : 0.f;
       id = li;
     }
     t.key[e] = s;
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(MetricsArgs a) {
   if (P <= 64) {
     metrics_short_lists(a, blockIdx.x, gridDim.x, s_vals);
   } else {
-  load_tile(t, scores, labels, docids, n_rows, u_pred, B, Lx, P, E, LPB);
+  load_tile(t, scores, labels, docids, n_rows, u_pred, B, Lx, P, E, LPB, &a);
 
   // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
   if (tid < LPB) {
@@ -218,6 +220,8 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
   const int tid = threadIdx.x;
   // the wave's row of partial sums lives in LDS (only the wave's first lane touches it): 48 accumulators per lane would
   // cost the kernel an occupancy step
+  const bool draw_ties = !u_pred && a.tie_seed != 0ull;
+  const unsigned int t_step = draw_ties ? tie_step_of(a) : 0u;
   float* my_row = s_vals + (tid >> 6) * nout;
   if ((tid & 63) < nout) my_row[tid & 63] = 0.f;
   for (long long b0 = (long long)blockIdx.x * kMetThreads; b0 < B; b0 += (long long)gridDim.x * kMetThreads) {
@@ -233,6 +237,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
         if (docids && docids[g] == n_rows) s[l] = kPaddingScore;
         lab[l] = labels[g];
         if (u_pred) u[l] = u_pred[b * Lx + l];
+        else if (draw_ties) u[l] = tie_uniform(a, t_step, b, l);
       }
     }
     const float w = list_weights ? list_weights[b] : 1.f;
@@ -402,9 +407,11 @@ int launch_metrics_now(const MetricsArgs& a, unsigned nblocks, hipStream_t st) {
 }
 
 // argument checks + launch geometry shared by ultr_metrics and ultr_metrics_deferred
+struct TieSpec { unsigned long long seed; unsigned int step; unsigned int* ctr; unsigned int slot_base; };
 static int prepare_metrics(const char* who, const float* scores, const float* labels, const int* docids, int n_rows,
                            const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h, int n_topn,
-                           int metric_mask, float max_label, float* out, float* ws, MetricsArgs* a, unsigned* nblocks) {
+                           int metric_mask, float max_label, float* out, float* ws, MetricsArgs* a, unsigned* nblocks,
+                           TieSpec ties = TieSpec{0ull, 0u, nullptr, 0u}) {
   ULTR_REQUIRE(scores && labels && out && ws && topn_h, ULTR_EINVAL, "%s: null pointer", who);
   ULTR_REQUIRE(B > 0 && Lx > 0, ULTR_EINVAL, "%s: bad sizes B=%d Lx=%d", who, B, Lx);
   ULTR_REQUIRE(Lx <= ULTR_MAX_SORT, ULTR_ELIMIT, "%s: list length %d > %d", who, Lx, ULTR_MAX_SORT);
@@ -423,6 +430,7 @@ static int prepare_metrics(const char* who, const float* scores, const float* la
   a->scores = scores; a->labels = labels; a->docids = docids; a->n_rows = n_rows; a->list_weights = list_weights;
   a->u_pred = u_pred; a->B = B; a->Lx = Lx; a->P = P; a->LPB = LPB; a->n_topn = n_topn;
   a->metric_mask = metric_mask; a->max_label = max_label; a->out = out; a->ws = ws;
+  a->tie_seed = ties.seed; a->tie_step = ties.step; a->tie_ctr = ties.ctr; a->tie_slot_base = ties.slot_base;
   *nblocks = (unsigned)((P <= 64 && cdiv(B, LPB) > kMetMaxBlocks) ? kMetMaxBlocks : cdiv(B, LPB));
   if (P <= 16 && B >= kLanesMinB)
     *nblocks = (unsigned)(cdiv(B, kMetThreads) > kLanesMaxBlocks ? kLanesMaxBlocks : cdiv(B, kMetThreads));
@@ -491,6 +499,44 @@ extern "C" int ultr_metrics_static(const float* scores, const float* labels, con
   const hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), as_stream(stream));
   ULTR_REQUIRE(e == hipSuccess, ULTR_EHIP, "ultr_metrics_static: hipMemsetAsync: %s", hipGetErrorString(e));
   return launch_metrics_now(a, nblocks, as_stream(stream));
+}
+
+extern "C" int ultr_metrics_ties(const float* scores, const float* labels, const int* docids, int n_rows,
+                                 const float* list_weights, int B, int Lx, const int* topn_h, int n_topn, int metric_mask,
+                                 float max_label, unsigned long long tie_seed, unsigned int tie_step,
+                                 unsigned int* tie_ctr, unsigned int tie_slot_base, float* out, float* ws, void* stream) {
+  ULTR_REQUIRE(tie_seed != 0ull, ULTR_EINVAL, "ultr_metrics_ties: tie_seed must not be 0 (0 means no tie shuffling)");
+  MetricsArgs a;
+  unsigned nblocks;
+  const int rc = prepare_metrics("ultr_metrics_ties", scores, labels, docids, n_rows, list_weights, nullptr, B, Lx, topn_h,
+                                 n_topn, metric_mask, max_label, out, ws, &a, &nblocks,
+                                 TieSpec{tie_seed, tie_step, tie_ctr, tie_slot_base});
+  if (rc) return rc;
+  return launch_metrics_now(a, nblocks, as_stream(stream));
+}
+
+extern "C" int ultr_metrics_ties_deferred(const float* scores, const float* labels, const int* docids, int n_rows,
+                                          const float* list_weights, int B, int Lx, const int* topn_h, int n_topn,
+                                          int metric_mask, float max_label, unsigned long long tie_seed,
+                                          unsigned int tie_step, unsigned int* tie_ctr, unsigned int tie_slot_base,
+                                          float* out, float* ws, void* stream) {
+  ULTR_REQUIRE(tie_seed != 0ull, ULTR_EINVAL, "ultr_metrics_ties_deferred: tie_seed must not be 0");
+  MetricsArgs a;
+  unsigned nblocks;
+  int rc = prepare_metrics("ultr_metrics_ties_deferred", scores, labels, docids, n_rows, list_weights, nullptr, B, Lx,
+                           topn_h, n_topn, metric_mask, max_label, out, ws, &a, &nblocks,
+                           TieSpec{tie_seed, tie_step, tie_ctr, tie_slot_base});
+  if (rc) return rc;
+  if (g_pending_metrics.on) {  // an earlier request nobody carried: it runs now, on its own
+    g_pending_metrics.on = false;
+    rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, as_stream(stream));
+    if (rc) return rc;
+  }
+  if (a.P > 64) return launch_metrics_now(a, nblocks, as_stream(stream));
+  g_pending_metrics.on = true;
+  g_pending_metrics.a = a;
+  g_pending_metrics.nblocks = nblocks;
+  return ULTR_OK;
 }
 
 extern "C" int ultr_metrics_deferred(const float* scores, const float* labels, const int* docids, int n_rows,

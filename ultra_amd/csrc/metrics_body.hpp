@@ -21,7 +21,21 @@ struct MetricsArgs {
   int topn[kMaxTopn];
   int metric_mask; float max_label;
   float* out; float* ws;
+  // tie-break uniforms drawn in the kernel when u_pred is NULL and tie_seed != 0 (sort_by_scores shuffles ties with
+  // fresh uniforms on every call, metric_utils.py:76-81): Philox4x32-10, counter (tie_slot_base + list, 'TIE', rank / 4,
+  // tie_step + *tie_ctr), key = tie_seed; the last workgroup of the launch bumps *tie_ctr, so the next call -- or the
+  // next replay of a captured graph -- draws new ones
+  unsigned long long tie_seed; unsigned int tie_step; unsigned int* tie_ctr; unsigned int tie_slot_base;
 };
+
+__device__ __forceinline__ unsigned int tie_step_of(const MetricsArgs& a) {
+  return a.tie_step + (a.tie_ctr ? __hip_atomic_load(a.tie_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+}
+__device__ __forceinline__ float tie_uniform(const MetricsArgs& a, unsigned int step, long long b, int r) {
+  const Philox4 rnd = philox4x32_10(a.tie_slot_base + (uint32_t)b, 0x544945u, (uint32_t)(r >> 2), step,
+                                    (uint32_t)a.tie_seed, (uint32_t)(a.tie_seed >> 32));
+  return u24(philox_word(rnd, r));
+}
 
 __device__ __forceinline__ bool goes_before(float sa, float ua, int ia, float sb, float ub, int ib, int Lx) {
   const bool fa = ia >= Lx, fb = ib >= Lx;  // fillers always sort last
@@ -46,6 +60,8 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
   const int nout = n_met * n_topn * 2;
   const int tid = threadIdx.x;
   float r_lab = 0.f, r_ilab = 0.f, r_w = 1.f;
+  const bool draw_ties = !u_pred && a.tie_seed != 0ull;
+  const unsigned int t_step = draw_ties ? tie_step_of(a) : 0u;
     // Short lists: a list is a group of P lanes inside one wave and never touches LDS.  The grid is capped
     // (kMetMaxBlocks): beyond that a block walks several groups of LPB lists and keeps its outputs in registers,
     // so the number of partial rows the last block has to add stays bounded.
@@ -66,7 +82,7 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
         s = scores[g];
         if (docids && docids[g] == n_rows) s = kPaddingScore;
         lb = labels ? labels[g] : 0.f;
-        uu = u_pred ? u_pred[(long long)b * Lx + r] : 0.f;
+        uu = u_pred ? u_pred[(long long)b * Lx + r] : draw_ties ? tie_uniform(a, t_step, b, r) : 0.f;
         id = r;
       }
       // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
@@ -211,6 +227,9 @@ __device__ __forceinline__ void metrics_finish(const MetricsArgs& a, int bid, in
     __shared__ float s_tmp[kMetThreads];
     reduce_rows<true>(rows, (int)nb, nout, 1 << 30, s_tmp, s_acc);
     if (tid < nout && ((tid & 1) == 0 || list_weights)) out[tid] = s_acc[tid] / (float)B;
+    // every workgroup has arrived, so every workgroup has read the tie counter: the next call draws fresh uniforms
+    if (tid == 0 && a.tie_ctr && !a.u_pred && a.tie_seed != 0ull)
+      __hip_atomic_fetch_add(a.tie_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

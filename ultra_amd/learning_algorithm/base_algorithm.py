@@ -147,12 +147,18 @@ class BaseAlgorithm(ABC):
         self.n_stats = self._n_stats()
         self.eval_plan = dev_metrics.MetricPlan(exp_settings['metrics'], exp_settings['metrics_topn'])
         self.train_plan = self.eval_plan
-        self.shuffle_ties = bool(exp_settings.get('metric_shuffle_ties', False))
+        # Ties between equal scores are broken by fresh uniforms on every metric evaluation, as in the reference
+        # (metric_utils.py:49-86: shuffle_ties=True is the default of every metric); the metric kernels draw them
+        # themselves (Philox keyed by the experiment seed, a device counter they advance).  'metric_shuffle_ties': false
+        # in the settings switches to index order.
+        self.shuffle_ties = bool(exp_settings.get('metric_shuffle_ties', True))
+        self._tie_seed = (int(exp_settings.get('seed') or 0) * 0x9E3779B97F4A7C15 + 0x7F4A7C15) % (1 << 64) or 1
         self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and \
             torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if self.world > 1 else 0
         self._eval_bufs = {}
         self._train_bufs = None
+        self._tie_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.saver = Saver(self)
         if not forward_only:
             if hparams.grad_strategy == 'sgd':
@@ -254,12 +260,11 @@ class BaseAlgorithm(ABC):
 
     def _train_metrics(self, tb, batch, scores, weighted, deferred=False):
         u = getattr(self, 'metric_uniforms', None)  # [B, L] tie-break uniforms supplied by the caller (tests)
-        if u is None and self.shuffle_ties:
-            u = torch.rand((batch.B, scores.shape[0]), dtype=torch.float32, device=self.device)
         tb['metric_u'] = u  # kept alive until the backward pass has carried a deferred request
+        ties = (self._tie_seed, 0, self._tie_ctr, self.rank * batch.B) if (u is None and self.shuffle_ties) else None
         dev_metrics.batch_metrics(self.train_plan, scores, batch.labels, batch.docids, batch.n_rows,
                                   tb['list_weights'] if weighted else None, tb['metrics'], tb['met_ws'], u,
-                                  deferred=deferred)
+                                  deferred=deferred, ties=ties)
 
     # ULTR_LOSS_RIDE=0: the loss kernel gets a launch of its own instead of riding with the backward pass's first one
     ride_loss = os.environ.get('ULTR_LOSS_RIDE', '1') != '0'
@@ -478,9 +483,9 @@ class BaseAlgorithm(ABC):
                   'ws': dev_metrics.metrics_workspace(B, self.eval_plan, self.device)}
             self._eval_bufs[B] = eb
         scores = self.ranking_model(Lx, batch, eb['scores'], is_training=False)
-        u = torch.rand((B, Lx), dtype=torch.float32, device=self.device) if self.shuffle_ties else None
+        ties = (self._tie_seed, 0, self._tie_ctr, 0) if self.shuffle_ties else None
         dev_metrics.batch_metrics(self.eval_plan, scores, batch.labels, batch.docids, batch.n_rows, None, eb['out'],
-                                  eb['ws'], u)
+                                  eb['ws'], getattr(self, 'metric_uniforms_eval', None), ties=ties)
         out = eb['out'].clone()
         tags = self.eval_plan.tags(False)
 

@@ -66,13 +66,24 @@ def metrics_workspace(B, plan, device):
 
 
 def batch_metrics(plan, scores_lb, labels_lb, docids_lb, n_rows, list_weights, out, ws, u_pred=None, max_label=None,
-                  deferred=False):
+                  deferred=False, ties=None):
     """scores/labels/docids position-major [L][B] device tensors -> out[plan.n_out] (device, in place).
 
     deferred=True parks the request: the next ``ultr_dnn_backward`` of this thread carries it inside one of its own
-    launches (``ultr_metrics_deferred``); every tensor passed here must stay alive until then."""
+    launches (``ultr_metrics_deferred``); every tensor passed here must stay alive until then.
+    ties=(seed, step, counter tensor | None, slot_base) with u_pred None: the kernel draws the tie-break uniforms itself
+    (``ultr_metrics_ties``), fresh ones on every call like sort_by_scores (metric_utils.py:76-81)."""
     L, B = scores_lb.shape
     ml = max_label if max_label is not None else (RankingMetricKey.MAX_LABEL or 0.0)
+    if u_pred is None and ties is not None:
+        seed, step, ctr, slot_base = ties
+        fn = _lib.lib().ultr_metrics_ties_deferred if deferred else _lib.lib().ultr_metrics_ties
+        _lib.check(fn(
+            _lib.ptr(scores_lb), _lib.ptr(labels_lb), _lib.ptr(docids_lb), int(n_rows), _lib.ptr(list_weights),
+            int(B), int(L), plan.topn_c, len(plan.topn), plan.mask, float(ml), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            int(step) & 0xFFFFFFFF, _lib.ptr(ctr), int(slot_base) & 0xFFFFFFFF, _lib.ptr(out), _lib.ptr(ws),
+            _lib.current_stream()), 'ultr_metrics_ties')
+        return out
     fn = _lib.lib().ultr_metrics_deferred if deferred else _lib.lib().ultr_metrics
     _lib.check(fn(
         _lib.ptr(scores_lb), _lib.ptr(labels_lb), _lib.ptr(docids_lb), int(n_rows), _lib.ptr(list_weights),
