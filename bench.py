@@ -210,6 +210,7 @@ def main():
     ap.add_argument('--force_collective', action='store_true',
                     help='single-GPU rehearsal of the multi-GPU launch path: a 1-rank RCCL group, all-reduce issued anyway')
     ap.add_argument('--algo_hparams', default='')
+    ap.add_argument('--override', default='', help='diagnostics only: e.g. algo=PairDebias,Q=20000 on top of --config')
     ap.add_argument('--prefetch', type=int, default=1,
                     help='feed hparam prefetch: batch t+1 is assembled inside the last launch of step t (every step still '
                          'assembles exactly one batch)')
@@ -240,7 +241,10 @@ def main():
     elif args.force_collective:
         torch.distributed.init_process_group('nccl', init_method='tcp://127.0.0.1:29577', rank=0, world_size=1,
                                              device_id=device)
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    for kv in filter(None, args.override.split(',')):  # diagnostics: swap one field of the named config
+        k, v = kv.split('=')
+        cfg[k] = type(cfg[k])(v)
     with contextlib.redirect_stdout(sys.stderr):  # the plugin classes print progress lines like the reference does
         data, exp, model, feed = build_world(cfg, args, device)
     use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 2)

@@ -376,6 +376,18 @@ int ultr_pd_update_ratios(float* t_plus, float* t_minus, int L, float* stats, fl
                           float regulation_p, float* old_out /* [2L] pre-update t+,t-; may be NULL */,
                           void* stream);
 
+/* The same two EM-state updates (regression_EM.py:151-155, pairwise_debias.py:162-171), parked on
+ * the calling thread instead of launched: the next ultr_clip_adagrad* call on this thread carries
+ * the request in its update launch (workgroup 0 applies it before it publishes the step's row; a
+ * parameter group of <= 4096 floats launches it first instead).  The pointers must stay valid
+ * until that call.  A second request, or ultr_em_update_flush, launches a parked one on `stream`.
+ * Pair lists too long for the riding body (PD with L > 16) run at once, as the call above. */
+int ultr_rem_update_propensity_deferred(float* propensity, int L, const float* stats, float em_step_size,
+                                        float* old_out, void* stream);
+int ultr_pd_update_ratios_deferred(float* t_plus, float* t_minus, int L, float* stats, float em_step_size,
+                                   float regulation_p, float* old_out, void* stream);
+int ultr_em_update_flush(void* stream);
+
 /* ---- metrics (metrics.py:215-323,445-481; sort metric_utils.py:49-86) --------------------
  * scores/labels [Lx][B] position-major.  docids (may be NULL) [Lx][B]: entries == n_rows get
  * PADDING_SCORE first (base_algorithm.py:64-87).  list_weights [B] or NULL (per-list weights).

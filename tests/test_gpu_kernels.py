@@ -516,6 +516,58 @@ def test_clip_adagrad(L, n, strategy, clip, l2):
     assert relerr(th.cpu().numpy(), want_t) < 1e-6
 
 
+@pytest.mark.parametrize('kind,Ls,n', [('rem', 10, 50000), ('rem', 10, 1000), ('rem', 64, 50000), ('pd', 10, 50000),
+                                       ('pd', 16, 9000), ('pd', 10, 1000), ('pd', 24, 50000), ('rem', 10, 0)])
+def test_em_update_rides_with_the_optimiser(L, kind, Ls, n):
+    """The parked EM-state update (ultr_*_deferred) against the immediate entry point: carried by the update launch of
+    the next ultr_clip_adagrad3 (n > 4096), launched first for a small group, at once for long lists, and by
+    ultr_em_update_flush when nothing carries it (n == 0 here).  Bit-exact: both run the same arithmetic."""
+    rng = np.random.RandomState(Ls + n % 97)
+    if kind == 'rem':
+        state = [rng.uniform(0.2, 0.95, size=Ls)]
+        stats = np.concatenate([[0.7, 256.0], rng.uniform(10, 200, size=3 * Ls), [0.0]])
+        n_old = Ls
+    else:
+        state = [rng.uniform(0.5, 1.5, size=Ls), rng.uniform(0.5, 1.5, size=Ls)]
+        stats = np.concatenate([rng.uniform(0.1, 5.0, size=Ls * Ls), [0.0]])
+        n_old = 2 * Ls
+    nn = max(n, 8)
+    theta, acc, g = rng.normal(size=nn), rng.uniform(0.1, 1.0, size=nn), rng.normal(scale=0.01, size=nn)
+    dn = dev([7.5], torch.float32)
+
+    def run(deferred):
+        st = [dev(x, torch.float32) for x in state]
+        sd = dev(stats, torch.float32)
+        row = torch.zeros(8 + n_old, device='cuda')  # [norm | .. | old state (8..)]
+        dst = torch.full((8 + n_old,), -5.0, device='cuda')
+        th, ac, gr = dev(theta, torch.float32), dev(acc, torch.float32), dev(g, torch.float32)
+        ws = torch.zeros(2048, device='cuda')
+        sfx = '_deferred' if deferred else ''
+        if kind == 'rem':
+            L.check(getattr(L.lib(), 'ultr_rem_update_propensity' + sfx)(
+                L.ptr(st[0]), Ls, L.ptr(sd), 0.05, L.ptr(row[8:]), stream(L)), 'remup')
+        else:
+            L.check(getattr(L.lib(), 'ultr_pd_update_ratios' + sfx)(
+                L.ptr(st[0]), L.ptr(st[1]), Ls, L.ptr(sd), 0.05, 1.0, L.ptr(row[8:]), stream(L)), 'pdup')
+        if n > 4096:
+            L.check(L.lib().ultr_clip_adagrad3(
+                L.ptr(th), L.ptr(ac), L.ptr(gr), n, L.ptr(dn), 2.0, 0.0, 1.5, 0.05, 0, L.ptr(row[0:1]), L.ptr(ws),
+                None, None, None, 0, None, 1.0, 0.0, 0.0, 0.0, None, None, 0, 0,
+                L.ptr(row), L.ptr(dst), row.numel(), stream(L)), 'opt3')
+        elif n > 0:
+            L.check(L.lib().ultr_clip_adagrad(L.ptr(th), L.ptr(ac), L.ptr(gr), n, L.ptr(dn), 2.0, 0.0, 1.5, 0.05, 0,
+                                              L.ptr(row[0:1]), L.ptr(ws), stream(L)), 'opt')
+        else:
+            L.check(L.lib().ultr_em_update_flush(stream(L)), 'flush')
+        torch.cuda.synchronize()
+        return [x.cpu().numpy() for x in st] + [sd.cpu().numpy(), row.cpu().numpy(), dst.cpu().numpy(), th.cpu().numpy()]
+    want, got = run(False), run(True)
+    for w, g_ in zip(want, got):
+        assert np.array_equal(w, g_, equal_nan=True)
+    if n > 4096:  # the published row holds the pre-update state and the norm
+        assert np.array_equal(got[-2][8:], np.concatenate(state).astype(np.float32)) and got[-2][0] == got[-3][0] > 0
+
+
 @pytest.mark.parametrize('with_small,with_sumsq,with_publish', [(True, True, True), (False, True, False),
                                                                 (True, False, True), (False, False, True)])
 def test_clip_adagrad3_fused_tail(L, with_small, with_sumsq, with_publish):

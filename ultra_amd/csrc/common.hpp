@@ -238,7 +238,7 @@ __device__ __forceinline__ bool last_block_arrive_sc1(unsigned int* counter, uns
 
 // ---- Philox4x32-10 -------------------------------------------------------------------------
 struct Philox4 {
-  uint32_t v[4];
+  uint32_t w0, w1, w2, w3;
 };
 __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                           uint32_t k0, uint32_t k1) {
@@ -255,17 +255,23 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
     k1 += 0xBB67AE85u;
   }
   Philox4 o;
-  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  o.w0 = c0; o.w1 = c1; o.w2 = c2; o.w3 = c3;
   return o;
 }
 // two 32-bit words -> double in [0,1), the genrand_res53 construction of CPython's random.random()
 __host__ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
-// word (r & 3) of a block, selected with compares: a run-time index into v[] can put the block into scratch memory
-// (measured: +13 us on a rider workgroup)
+// word (r & 3) of a block, selected with compares between VALUES.  Left to itself the optimiser folds a select between
+// the four member loads into one load at a computed offset, which keeps the block in private memory: promoted to LDS,
+// indexed by the work-item's flat id, which is derived from the dispatch packet at the top of the kernel (measured:
+// +13 us on a 12 us launch).  The empty asm makes the four words opaque register values first.
 __host__ __device__ __forceinline__ uint32_t philox_word(const Philox4& b, int r) {
-  return (r & 2) ? ((r & 1) ? b.v[3] : b.v[2]) : ((r & 1) ? b.v[1] : b.v[0]);
+  uint32_t a0 = b.w0, a1 = b.w1, a2 = b.w2, a3 = b.w3;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+#endif
+  return (r & 2) ? ((r & 1) ? a3 : a2) : ((r & 1) ? a1 : a0);
 }
 // 32-bit word -> float in [0,1) (24 bits)
 __host__ __device__ __forceinline__ float u24(uint32_t a) { return (float)(a >> 8) * (1.0f / 16777216.0f); }

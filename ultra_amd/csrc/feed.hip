@@ -21,7 +21,7 @@ struct PhiloxDraws {
       blk = philox4x32_10(c0, c1, (uint32_t)b, c3, k0, k1);
       cur_block = b;
     }
-    return (d & 1) ? u53(blk.v[2], blk.v[3]) : u53(blk.v[0], blk.v[1]);
+    return (d & 1) ? u53(blk.w2, blk.w3) : u53(blk.w0, blk.w1);
   }
 };
 
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) click_small_kernel(int model, const float
         u = uniforms[i * L + r];
       } else {
         const Philox4 bd = philox4x32_10((uint32_t)i, 0u, (uint32_t)(r >> 1), step, (uint32_t)seed, (uint32_t)(seed >> 32));
-        u = (r & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+        u = (r & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
       }
     }
     bool c = false;
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) online_rerank_click_kernel(OnlineArgs a) 
         const unsigned int stp = a.step + (a.step_ctr ? *a.step_ctr : 0u);
         const Philox4 bd = philox4x32_10(a.slot_base + (uint32_t)b, 0xFFFFFFFFu, (uint32_t)(p >> 1), stp,
                                          (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-        u = (p & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+        u = (p & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
       }
       u = u > 8.673617379884035e-19 ? u : 8.673617379884035e-19;  // 2^-60: keeps the noise finite
       key = (double)a.tau * key - log(-log(u));
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) online_rerank_click_kernel(OnlineArgs a) 
         u = a.uniforms[(long long)b * a.L + lane];
       } else {  // draw `lane` of the stream (slot, round, *, step): words (2 lane, 2 lane + 1) of its block sequence
         const Philox4 bd = philox4x32_10(slot, (uint32_t)round, (uint32_t)(lane >> 1), step, k0, k1);
-        u = (lane & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+        u = (lane & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
       }
     }
     bool c = false;
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) online_rerank_click_small_kernel(OnlineAr
       u = a.rank_uniforms[b * Lmax + r];
     } else {
       const Philox4 bd = philox4x32_10(slot, 0xFFFFFFFFu, (uint32_t)(r >> 1), step, k0, k1);
-      u = (r & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+      u = (r & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
     }
     u = u > 8.673617379884035e-19 ? u : 8.673617379884035e-19;
     key = (double)a.tau * key - log(-log(u));
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) online_rerank_click_small_kernel(OnlineAr
           u = a.uniforms[b * a.L + r];
         } else {
           const Philox4 bd = philox4x32_10(slot, (uint32_t)round, (uint32_t)(r >> 1), step, k0, k1);
-          u = (r & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+          u = (r & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
         }
       }
       bool c = false;

@@ -128,7 +128,7 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
       const int a = a0 + ai;
       // draw 0 (words 0,1 of block 0) picks the list: int(random.random() * length) (:132)
       const Philox4 b0 = philox4x32_10(slot, (uint32_t)a, 0u, step, k0, k1);
-      i = (int)(u53(b0.v[0], b0.v[1]) * (double)Q);
+      i = (int)(u53(b0.w0, b0.w1) * (double)Q);
       i = i < Q ? i : Q - 1;
       bool c = false;
       doc = -1;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
         } else {
           const int d = 1 + pos;  // draws 1..L are the click draws (:87)
           const Philox4 bd = philox4x32_10(slot, (uint32_t)a, (uint32_t)(d >> 1), step, k0, k1);
-          u = (d & 1) ? u53(bd.v[2], bd.v[3]) : u53(bd.v[0], bd.v[1]);
+          u = (d & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
           if (tables_in_regs) {
             int rel = lab > 0.f ? (int)lab : 0;     // click_threshold()'s rule: int() truncation, clamp to the table
             rel = rel < t.n_cp ? rel : t.n_cp - 1;

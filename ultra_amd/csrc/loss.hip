@@ -695,6 +695,41 @@ extern "C" int ultr_loss_rem_deferred(const float* scores, const float* clicks, 
   return ULTR_OK;
 }
 
+namespace ultr {
+thread_local PendingEm g_pending_em = {};
+__global__ void __launch_bounds__(64) em_update_kernel(EmUpdate e) {
+  if (e.kind == ULTR_RIDE_REM) rem_update_body(e);
+  else pd_update_body(e);
+}
+int launch_em_now(const EmUpdate& e, hipStream_t st) {
+  {
+    ProfScope prof_(e.kind == ULTR_RIDE_REM ? "rem_update_kernel" : "pd_update_kernel", st);
+    hipLaunchKernelGGL(em_update_kernel, dim3(1), dim3(64), 0, st, e);
+  }
+  return check_launch("em_update_kernel");
+}
+}  // namespace ultr
+
+extern "C" int ultr_em_update_flush(void* stream) {
+  if (!g_pending_em.on) return ULTR_OK;
+  g_pending_em.on = false;
+  return launch_em_now(g_pending_em.e, as_stream(stream));
+}
+
+extern "C" int ultr_rem_update_propensity_deferred(float* propensity, int L, const float* stats, float em_step_size,
+                                                   float* old_out, void* stream) {
+  ULTR_REQUIRE(propensity && stats && L > 0 && L <= ULTR_MAX_LIST, ULTR_EINVAL, "ultr_rem_update_propensity_deferred: bad args");
+  int rc = ultr_em_update_flush(stream);  // an earlier request nobody carried runs first
+  if (rc) return rc;
+  const EmUpdate e{ULTR_RIDE_REM, propensity, nullptr, L, const_cast<float*>(stats), em_step_size, 0.f, old_out};
+  g_pending_em.on = true;
+  g_pending_em.e = e;
+  return ULTR_OK;
+}
+
+extern "C" int ultr_pd_update_ratios(float* t_plus, float* t_minus, int L, float* stats, float em_step_size,
+                                     float regulation_p, float* old_out, void* stream);
+
 extern "C" int ultr_rem_update_propensity(float* propensity, int L, const float* stats, float em_step_size,
                                           float* old_out, void* stream) {
   ULTR_REQUIRE(propensity && stats && L > 0 && L <= ULTR_MAX_LIST, ULTR_EINVAL, "ultr_rem_update_propensity: bad args");
@@ -742,6 +777,18 @@ extern "C" int ultr_loss_pd_deferred(const float* scores, const float* clicks, i
   g_pending_loss.kind = ULTR_RIDE_PD;
   g_pending_loss.pd = PdArgs{scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws};
   g_pending_loss.nblocks = small_blocks(B);
+  return ULTR_OK;
+}
+
+extern "C" int ultr_pd_update_ratios_deferred(float* t_plus, float* t_minus, int L, float* stats, float em_step_size,
+                                              float regulation_p, float* old_out, void* stream) {
+  ULTR_REQUIRE(t_plus && t_minus && stats && L > 0 && L <= kPdMaxL, ULTR_EINVAL, "ultr_pd_update_ratios_deferred: bad args");
+  int rc = ultr_em_update_flush(stream);
+  if (rc) return rc;
+  if (L > kEmMaxL)  // only the short-list body can ride
+    return ultr_pd_update_ratios(t_plus, t_minus, L, stats, em_step_size, regulation_p, old_out, stream);
+  g_pending_em.on = true;
+  g_pending_em.e = EmUpdate{ULTR_RIDE_PD, t_plus, t_minus, L, stats, em_step_size, regulation_p, old_out};
   return ULTR_OK;
 }
 

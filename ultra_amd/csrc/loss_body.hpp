@@ -496,6 +496,65 @@ __device__ __forceinline__ void pd_loss_small_body(const PdArgs& a, unsigned int
 // A loss request parked by ultr_loss_{dla,ipw,rem,pd}_deferred until the next ultr_dnn_backward of this host thread
 // carries it in its first launch.
 enum { ULTR_RIDE_NONE = 0, ULTR_RIDE_DLA = 1, ULTR_RIDE_IPW = 2, ULTR_RIDE_REM = 3, ULTR_RIDE_PD = 4 };
+
+// The EM-state updates of regression-EM and pairwise debiasing (a handful of floats) as device functions of ONE
+// workgroup: launches of their own (rem_update_kernel, pd_update_kernel), or carried by the optimiser's update launch
+// (ultr_*_update_*_deferred): they need only the all-reduced statistics, which exist before that launch.
+constexpr int kEmMaxL = 16;
+struct EmUpdate {
+  int kind;            // 0 none, ULTR_RIDE_REM, ULTR_RIDE_PD
+  float* a; float* b;  // REM: propensity, - ; PD: t_plus, t_minus
+  int L; float* stats; float step, reg_p; float* old_out;
+};
+// p <- (1-s) p + s * stats[2+l]/stats[1]  (regression_EM.py:151-155)
+__device__ __forceinline__ void rem_update_body(const EmUpdate& e) {
+  const int l = threadIdx.x;
+  if (l < e.L && e.old_out) e.old_out[l] = e.a[l];
+  if (l < e.L) e.a[l] = (1.f - e.step) * e.a[l] + e.step * (e.stats[2 + l] / e.stats[1]);
+}
+// t+_i <- (1-s) t+_i + s (A_i/A_0)^(1/(p+1)), A_i = sum_j l_ij/t-_j ; t-_j likewise (pairwise_debias.py:162-171); also the
+// loss from the (all-reduced) pair matrix into stats[L*L].  L <= kEmMaxL here (longer lists: pd_update_kernel).
+__device__ __forceinline__ void pd_update_body(const EmUpdate& e) {
+  __shared__ float A[kEmMaxL], Am[kEmMaxL], tp[kEmMaxL], tm[kEmMaxL];
+  __shared__ float s_l[kEmMaxL * kEmMaxL];
+  const int k = threadIdx.x, L = e.L;
+  for (int i = k; i < L * L; i += blockDim.x) s_l[i] = e.stats[i];
+  if (k < L) {
+    tp[k] = e.a[k];
+    tm[k] = e.b[k];
+    if (e.old_out) {
+      e.old_out[k] = tp[k];
+      e.old_out[L + k] = tm[k];
+    }
+  }
+  __syncthreads();
+  float row = 0.f;
+  if (k < L) {
+    float a = 0.f, am = 0.f;
+    for (int j = 0; j < L; ++j) {
+      if (j == k) continue;
+      a += s_l[k * L + j] / tm[j];
+      am += s_l[j * L + k] / tp[j];
+      row += s_l[k * L + j] / tp[k] / tm[j];
+    }
+    A[k] = a;
+    Am[k] = am;
+  }
+  __syncthreads();
+  if (k < L) {
+    const float ex = 1.f / (e.reg_p + 1.f);
+    e.a[k] = (1.f - e.step) * tp[k] + e.step * powf(A[k] / A[0], ex);
+    e.b[k] = (1.f - e.step) * tm[k] + e.step * powf(Am[k] / Am[0], ex);
+  }
+  if (k < 64) {
+    const float loss = wave_sum(row);
+    if (k == 0) e.stats[L * L] = loss;
+  }
+}
+struct PendingEm { bool on; EmUpdate e; };
+extern thread_local PendingEm g_pending_em;
+int launch_em_now(const EmUpdate& e, hipStream_t st);  // loss.hip
+
 struct PendingLoss {
   int kind;
   DlaArgs dla;

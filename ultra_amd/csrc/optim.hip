@@ -95,6 +95,12 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
     if (threadIdx.x == 0 && idx >= 0 && idx < o.pub_n) o.pub_dst[idx] = rider.out_norm[0];
     return;
   }
+  if (bid == 0 && o.em.kind != 0) {  // a handful of floats of EM state; its outputs are part of the row published below
+    if (o.em.kind == ULTR_RIDE_REM) rem_update_body(o.em);
+    else pd_update_body(o.em);
+    __threadfence_block();
+    __syncthreads();
+  }
   const float sc = eff_scale(denom, scale_const);
   const long long nblk = nbid - (rider.n > 0 ? 1 : 0);
   // The block's first (usually only) batch of gradient / parameter / accumulator values is requested before the norm
@@ -203,6 +209,15 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
   ULTR_REQUIRE(strategy == ULTR_OPT_ADAGRAD || strategy == ULTR_OPT_SGD, ULTR_EINVAL,
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
+  if (g_pending_em.on) {  // a parked EM-state update: carried by the big update launch, else a launch of its own now
+    g_pending_em.on = false;
+    if (n > 4096) {
+      o.em = g_pending_em.e;
+    } else {
+      const int rc = launch_em_now(g_pending_em.e, as_stream(stream));
+      if (rc) return rc;
+    }
+  }
   if (n <= 4096) {
     ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0 && o.tr.n == 0 && o.a_blocks == 0, ULTR_EINVAL,
                  "ultr_clip_adagrad: the fused options need a main group of more than 4096 parameters");

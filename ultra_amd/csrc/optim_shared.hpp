@@ -1,6 +1,7 @@
 // Optimiser types shared by optim.hip and fused.hip (the fused step's update call also refreshes the transposed weights).
 #pragma once
 #include "feed_body.hpp"
+#include "loss_body.hpp"
 
 namespace ultr {
 
@@ -52,6 +53,8 @@ struct TailOpts {
   // a_blocks > 0: the assembly of the NEXT batch rides with the update launch as its first a_pad workgroups (nothing
   // reads the current batch any more, so it may land in the same buffers; ultr_batch_assemble_deferred)
   AssembleArgs a; int a_blocks, a_pad;
+  // em.kind != 0: the EM-state update of regression-EM / pairwise debiasing, run by workgroup 0 before it publishes
+  EmUpdate em;
 };
 
 int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom, float scale_const,

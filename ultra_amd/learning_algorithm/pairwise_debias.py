@@ -59,9 +59,10 @@ class PairDebias(BaseAlgorithm):
         h, L = self.hparams, self.rank_list_size
         if h.l2_loss > 0:
             tb['local'][2:3].copy_((self.model.params[:self.n_params] ** 2).sum().reshape(1) * 0.5)
-        _lib.check(_lib.lib().ultr_pd_update_ratios(
+        # parked: the optimiser's update launch below applies it (one launch fewer per step)
+        _lib.check(_lib.lib().ultr_pd_update_ratios_deferred(
             _lib.ptr(self.t_plus), _lib.ptr(self.t_minus), L, _lib.ptr(tb['stats']), float(h.EM_step_size),
-            float(h.regulation_p), _lib.ptr(tb['local'][8:]), _lib.current_stream()), 'ultr_pd_update_ratios')
+            float(h.regulation_p), _lib.ptr(tb['local'][8:]), _lib.current_stream()), 'ultr_pd_update_ratios_deferred')
         # the loss is a batch SUM (:151-159): no normaliser
         self._clip_adagrad(self.model.params, self.acc, tb['grads'], self.n_total, None, 1.0,
                            h.l2_loss if h.l2_loss > 0 else 0.0, h.max_gradient_norm if h.max_gradient_norm > 0 else 0.0,

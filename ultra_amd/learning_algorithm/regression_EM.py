@@ -61,9 +61,10 @@ class RegressionEM(BaseAlgorithm):
         h, L = self.hparams, self.rank_list_size
         if h.l2_loss > 0:
             tb['local'][2:3].copy_((self.model.params ** 2).sum().reshape(1) * 0.5)
-        _lib.check(_lib.lib().ultr_rem_update_propensity(_lib.ptr(self.propensity), L, _lib.ptr(tb['stats']),
-                                                         float(h.EM_step_size), _lib.ptr(tb['local'][8:]),
-                                                         _lib.current_stream()), 'ultr_rem_update_propensity')
+        # parked: the optimiser's update launch below applies it (one launch fewer per step)
+        _lib.check(_lib.lib().ultr_rem_update_propensity_deferred(
+            _lib.ptr(self.propensity), L, _lib.ptr(tb['stats']), float(h.EM_step_size), _lib.ptr(tb['local'][8:]),
+            _lib.current_stream()), 'ultr_rem_update_propensity_deferred')
         # mean over the (global) batch: divide by stats[1] = B (regression_EM.py:159); all trainables incl. the bias
         self._clip_adagrad(self.model.params, self.acc, tb['grads'], self.n_total, tb['stats'][1:2], 1.0,
                            h.l2_loss if h.l2_loss > 0 else 0.0, h.max_gradient_norm if h.max_gradient_norm > 0 else 0.0,
