@@ -166,6 +166,36 @@ def test_click_kernels_bulk_and_philox(L, cascade):
     assert fn(L.ptr(dev(labels)), 0, Ls, L.ptr(exam), 10, L.ptr(cp), 5, None, 0, 0, L.ptr(out), stream(L)) == 0
 
 
+@pytest.mark.parametrize('model_file,Ls', [('pbm_0.1_1.0_4_1.0.json', 10), ('cascade_0.1_1.0_4_1.0.json', 10),
+                                           ('ubm_0.1_1_4_1.0.json', 13), ('pbm_0.1_1.0_4_1.0.json', 16),
+                                           ('cascade_0.1_1.0_4_1.0.json', 7), ('pbm_0.1_1.0_4_1.0.json', 1)])
+def test_click_kernel_many_lists(L, model_file, Ls):
+    """From 32768 lists on (Philox draws, L <= 16) a lane owns a whole list: the same clicks, bit for bit, as the
+    lane-per-element kernel gives for a prefix of the lists, and as the oracle's restatement of the stream for the last
+    ones (a ragged last tile: n is neither a multiple of 256 nor n L of 4)."""
+    g = load_json(model_file)
+    rng = np.random.RandomState(Ls)
+    n, n_small = 40001 + (Ls & 1), 20000
+    labels = rng.choice(6, size=(n, Ls)).astype(np.float32)
+    labels[::17, 0] = -1.0
+    kind, exam, n_exam, cp = _device_click_model(g, Ls)
+    lab = dev(labels)
+    out = torch.full((n, Ls), -1.0, dtype=torch.float32, device='cuda')
+    small = torch.empty((n_small, Ls), dtype=torch.float32, device='cuda')
+    seed, step = 0xABCDEF0123456789, 11
+    L.check(L.lib().ultr_click_sample(kind, L.ptr(lab), n, Ls, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), None, seed, step,
+                                      L.ptr(out), stream(L)), 'click')
+    L.check(L.lib().ultr_click_sample(kind, L.ptr(lab), n_small, Ls, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), None, seed,
+                                      step, L.ptr(small), stream(L)), 'click')
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:n_small], small.cpu().numpy())
+    assert set(np.unique(got).tolist()) <= {0.0, 1.0} and 0.02 < got.mean() < 0.7
+    for i in (n_small, n - 300, n - 2, n - 1):
+        ui = O.philox_uniforms(seed, step, i, 0, Ls)
+        assert got[i].tolist() == [float(c) for c in O.sample_clicks_one_list(
+            g['model_name'], g['click_prob'], g['exam_prob'], list(labels[i]), ui)]
+
+
 # ------------------------------------------------------------------------------------------------
 # batch assembly
 # ------------------------------------------------------------------------------------------------
@@ -278,8 +308,10 @@ def _loss_ws(L, B, Ls):
     return keep(torch.zeros(L.lib().ultr_loss_workspace_floats(B, Ls), dtype=torch.float32, device='cuda'))
 
 
-@pytest.mark.parametrize('B,Ls', [(256, 10), (1000, 9), (3, 1), (5000, 16), (40000, 10), (300, 24), (70000, 20)])  # L > 16: list per thread, capped grid
-@pytest.mark.parametrize('loss_func,prob,maxw', [(0, 0, -1.0), (1, 0, -1.0), (0, 1, 3.0)])
+# L > 16: list per thread, capped grid; B >= 32768 with L <= 16 and the default softmax pair: one lane per list
+@pytest.mark.parametrize('B,Ls', [(256, 10), (1000, 9), (3, 1), (5000, 16), (40000, 10), (300, 24), (70000, 20),
+                                  (33001, 7), (140000, 16), (32768, 1)])
+@pytest.mark.parametrize('loss_func,prob,maxw', [(0, 0, -1.0), (1, 0, -1.0), (0, 1, 3.0), (0, 0, 3.0)])
 def test_dla_loss_kernel(L, B, Ls, loss_func, prob, maxw):
     rng = np.random.RandomState(B + Ls)
     scores, clicks = _scores_clicks(rng, B, Ls)

@@ -87,6 +87,74 @@ __global__ void __launch_bounds__(256) click_small_kernel(int model, const float
   }
 }
 
+// Very many short lists (exactly LT <= 16 ranks, Philox draws): one lane per LIST.  The 16-lane kernel above evaluates
+// one whole Philox block per (list, rank) and uses half of it, and runs out of issue slots at ~1.4 TB/s; here a list
+// costs LT / 2 blocks.  The list-major rows of 256 lists are one contiguous run: they cross LDS so that every global
+// access is a full float4 row per lane group (row stride LT | 1 words in LDS: conflict-free for the per-list walk).
+// Same draws and thresholds as click_kernel: bit-identical clicks.
+constexpr long long kClickListsMinN = 32768;
+template <int LT>
+__global__ void __launch_bounds__(256) click_lists_kernel(int model, const float* __restrict__ labels, long long n,
+                                                          ClickTables t, unsigned long long seed, unsigned int step,
+                                                          float* __restrict__ clicks) {
+  constexpr int PS = LT | 1;
+  __shared__ float s_t[256 * PS];
+  const int tid = threadIdx.x;
+  const long long ntile = (n + 255) / 256;
+  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long long i0 = tile * 256;
+    const int cnt = (int)(n - i0 < 256 ? n - i0 : 256);        // lists in this tile
+    const float* __restrict__ src = labels + i0 * LT;           // 16-byte aligned: i0 is a multiple of 256
+    float* __restrict__ dst = clicks + i0 * LT;
+    const int nel = cnt * LT;
+    for (int e4 = tid; e4 < (nel >> 2); e4 += 256) {
+      const float4 v = reinterpret_cast<const float4*>(src)[e4];
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = 4 * e4 + q;
+        s_t[(e / LT) * PS + e % LT] = vv[q];
+      }
+    }
+    for (int e = (nel & ~3) + tid; e < nel; e += 256) s_t[(e / LT) * PS + e % LT] = src[e];
+    __syncthreads();
+    if (tid < cnt) {
+      const long long i = i0 + tid;
+      bool has_click = false;
+      int last = -1;
+      Philox4 bd{};
+#pragma unroll
+      for (int r = 0; r < LT; ++r) {
+        if ((r & 1) == 0) bd = philox4x32_10((uint32_t)i, 0u, (uint32_t)(r >> 1), step, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const double u = (r & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);  // a draw at EVERY rank (click_models.py:208)
+        const float lab = s_t[tid * PS + r];
+        const bool c = u < click_threshold(t, model, r, lab, last);
+        s_t[tid * PS + r] = (c && !(model == ULTR_CLICK_CASCADE && has_click)) ? 1.f : 0.f;
+        has_click = has_click || c;
+        if (c) last = r;
+      }
+    }
+    __syncthreads();
+    for (int e4 = tid; e4 < (nel >> 2); e4 += 256) {
+      float vv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = 4 * e4 + q;
+        vv[q] = s_t[(e / LT) * PS + e % LT];
+      }
+      reinterpret_cast<float4*>(dst)[e4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    for (int e = (nel & ~3) + tid; e < nel; e += 256) dst[e] = s_t[(e / LT) * PS + e % LT];
+    __syncthreads();
+  }
+}
+template <int LT>
+static void launch_click_lists(int model, const float* labels, long long n, int L, const ClickTables& t,
+                               unsigned long long seed, unsigned int step, float* clicks, unsigned nb, hipStream_t st) {
+  if (L == LT) hipLaunchKernelGGL(click_lists_kernel<LT>, dim3(nb), dim3(256), 0, st, model, labels, n, t, seed, step, clicks);
+  else if constexpr (LT > 1) launch_click_lists<LT - 1>(model, labels, n, L, t, seed, step, clicks, nb, st);
+}
+
 // Evaluate one candidate: pick the list, sample its clicks.  Returns the click bit mask.
 template <typename DrawFn>
 __device__ __forceinline__ unsigned long long eval_candidate(DrawFn&& draw, const int* __restrict__ initial_list,
@@ -421,6 +489,12 @@ extern "C" int ultr_click_sample(int click_model, const float* labels, long long
   ULTR_REQUIRE(n < (1ll << 32), ULTR_ELIMIT, "ultr_click_sample: n=%lld exceeds the 32-bit Philox list counter", n);
   if (n == 0) return ULTR_OK;
   ClickTables t{exam, n_exam, click_prob, n_click_prob};
+  if (L <= 16 && !uniforms && n >= kClickListsMinN && ((uintptr_t)labels % 16 == 0) && ((uintptr_t)clicks % 16 == 0)) {
+    const long long blocks = cdiv(n, 256) < 8192 ? cdiv(n, 256) : 8192;
+    ultr::ProfScope prof_("click_kernel", as_stream(stream));
+    launch_click_lists<16>(click_model, labels, n, L, t, seed, stream_step, clicks, (unsigned)blocks, as_stream(stream));
+    return check_launch("click_lists_kernel");
+  }
   if (L <= 16) {
     const long long blocks = cdiv(n, 16) < 65536 ? cdiv(n, 16) : 65536;  // capped grid, block-strided beyond
     ultr::ProfScope prof_("click_kernel", as_stream(stream));

@@ -236,6 +236,22 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(DlaArgs a)
   dla_loss_small_body(a, blockIdx.x, gridDim.x, s_acc, s_part, s_tower);
 }
 
+// Many short lists (B >= kDlaListsMinB, L <= 16): one lane per list, body in loss_body.hpp.
+constexpr int kDlaListsMinB = 32768;
+constexpr int kDlaListsMaxBlocks = 512;  // one partial row per workgroup for the last one to add
+template <int LT>
+__global__ void __launch_bounds__(kLossThreads) dla_loss_lists_kernel(DlaArgs a) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  __shared__ float s_tower[4 * 16];
+  dla_loss_lists_body<LT>(a, blockIdx.x, gridDim.x, s_acc, s_part, s_tower);
+}
+template <int LT>
+static void launch_dla_lists(const DlaArgs& a, unsigned nb, hipStream_t st) {
+  if (a.L == LT) hipLaunchKernelGGL(dla_loss_lists_kernel<LT>, dim3(nb), dim3(kLossThreads), 0, st, a);
+  else if constexpr (LT > 1) launch_dla_lists<LT - 1>(a, nb, st);
+}
+
 // ------------------------------------------------------------------------------------------
 // Regression-EM
 // stats: [0] sum loss_b [1] B [2+l] M-step numerator [2+L+l] sum ranker_label [2+2L+l] sum clicks
@@ -609,8 +625,16 @@ extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, in
   if (rc) return rc;
   rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
   if (rc) return rc;
-  // Short lists: a 16-lane group per list (every lane busy: one exp per lane instead of L per thread).  Measured at
-  // 2^20 lists of 10: 98 us against 139 us for the list-per-thread kernel below (222 VGPRs, two waves per SIMD).
+  // Short lists: a 16-lane group per list (every lane busy: one exp per lane instead of L per thread); it is also the body
+  // other launches can carry.  Very many of them: one lane per list, compiled for the exact list length.
+  if (L <= 16 && B >= kDlaListsMinB && B <= (1 << 30) && a.loss_func == ULTR_LOSS_SOFTMAX && a.prob_kind == ULTR_PROB_SOFTMAX) {  // one lane per list (measured at 2^20 lists of 10: see profiles/*hbm_kernels.txt)
+    const unsigned nb = (unsigned)(cdiv(B, kLossThreads) < kDlaListsMaxBlocks ? cdiv(B, kLossThreads) : kDlaListsMaxBlocks);
+    {
+      ultr::ProfScope prof_("dla_loss_lists_kernel", as_stream(stream));
+      launch_dla_lists<16>(a, nb, as_stream(stream));
+    }
+    return check_launch("dla_loss_lists_kernel");
+  }
   if (L <= 16) {
     PendingLoss p{};
     p.kind = ULTR_RIDE_DLA; p.dla = a; p.nblocks = small_blocks(B);

@@ -143,6 +143,30 @@ __device__ __forceinline__ DlaLane dla_lane(float o, float c, float pw, bool liv
   return v;
 }
 
+// The waves' partial rows (s_part) -> the block's row -> the last block's totals, and there the chain through the
+// propensity tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l.  s_tower = [pre | logit | logp | pw][16].
+__device__ __forceinline__ void dla_stats_tail(const DlaArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                               float* s_part, const float* s_tower) {
+  const int L = a.L, loss_func = a.loss_func, tid = threadIdx.x;
+  BlockStats bs{s_part};
+  bs.combine(s_acc, 4 + 3 * L, 1 << 30);
+  if (finish_stats(s_acc, 4 + 3 * L, 1 << 30, a.ws, a.stats, bid, nb)) {
+    if (tid < L) a.stats[4 + tid] = s_tower[3 * 16 + tid];
+    if (tid < 64) {
+      float dpre = 0.f;  // one rank per lane, the bias gradient is their wave sum
+      if (tid < L) {
+        const int l = tid;
+        const float dlogit = loss_func == ULTR_LOSS_SOFTMAX ? expf(s_tower[2 * 16 + l]) * s_acc[3] - s_acc[4 + 2 * L + l]
+                                                            : s_acc[4 + 2 * L + l];
+        dpre = dlogit * (s_tower[0 * 16 + l] > 0.f ? 1.f : s_tower[1 * 16 + l] + 1.f);
+        a.prop_grads[l] = dpre;
+      }
+      const float db = wave_sum(dpre);
+      if (tid == 0) a.prop_grads[L] = db;
+    }
+  }
+}
+
 // Block `bid` of `nb` (256 threads each) of the short-list DLA loss.  s_acc [kMaxStat], s_part [4 * kMaxStat],
 // s_tower [4 * 16] are LDS.
 __device__ __forceinline__ void dla_loss_small_body(const DlaArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
@@ -224,23 +248,104 @@ __device__ __forceinline__ void dla_loss_small_body(const DlaArgs& a, unsigned i
     mine[4 + L + lane] = rws;
     mine[4 + 2 * L + lane] = cols;
   }
-  BlockStats bs{s_part};
-  bs.combine(s_acc, 4 + 3 * L, 1 << 30);
-  if (finish_stats(s_acc, 4 + 3 * L, 1 << 30, a.ws, a.stats, bid, nb)) {
-    if (tid < L) a.stats[4 + tid] = s_tower[3 * 16 + tid];
-    if (tid < 64) {  // chain through the tower's ELU: d pre_l = d logit_l * ELU'(pre_l); d b = sum_l d pre_l
-      float dpre = 0.f;  // one rank per lane, the bias gradient is their wave sum
-      if (tid < L) {
-        const int l = tid;
-        const float dlogit = loss_func == ULTR_LOSS_SOFTMAX ? expf(s_tower[2 * 16 + l]) * s_acc[3] - s_acc[4 + 2 * L + l]
-                                                            : s_acc[4 + 2 * L + l];
-        dpre = dlogit * (s_tower[0 * 16 + l] > 0.f ? 1.f : s_tower[1 * 16 + l] + 1.f);
-        a.prop_grads[l] = dpre;
-      }
-      const float db = wave_sum(dpre);
-      if (tid == 0) a.prop_grads[L] = db;
+  dla_stats_tail(a, bid, nb, s_acc, s_part, s_tower);
+}
+
+// DLA for MANY short lists (exactly LT <= 16 ranks; softmax loss with softmax probabilities, the defaults: the other
+// variants keep the 16-lane body): one lane per LIST, its LT scores and clicks in registers, so every
+// load and store is a full 256-byte row per wave and the per-list softmaxes are plain register arithmetic (the 16-lane
+// body above spends ~200 wave instructions per 4 lists and runs out of issue slots long before HBM bandwidth).  The
+// per-rank batch sums stay in registers over the grid-stride walk and meet once at the end.  Same statistics row, same
+// hardware exp / log / rcp as dla_lane; sums over a list run rank 0..LT-1 in order (the 16-lane body adds them as a
+// butterfly), so results agree with it to rounding, not to the bit.
+template <int LT>
+__device__ __forceinline__ void dla_loss_lists_body(const DlaArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                                    float* s_part, float* s_tower) {
+#pragma clang fp contract(off)
+  const float* __restrict__ scores = a.scores;
+  const float* __restrict__ clicks = a.clicks;
+  const int B = a.B;
+  const float max_pw = a.max_pw;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const DlaTower tw = dla_tower(a.prop_params, LT, tid & 15, ULTR_PROB_SOFTMAX, max_pw);
+  if (tid < 16) {
+    s_tower[0 * 16 + tid] = tw.pre;
+    s_tower[1 * 16 + tid] = tw.logit;
+    s_tower[2 * 16 + tid] = tw.logp;
+    s_tower[3 * 16 + tid] = tw.pw;
+  }
+  __syncthreads();
+  float pw[LT], rws[LT], col[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    pw[l] = s_tower[3 * 16 + l];
+    rws[l] = 0.f;
+    col[l] = 0.f;
+  }
+  float rank_num = 0.f, rank_den = 0.f, exam_num = 0.f, exam_den = 0.f;
+  // Addresses: a uniform row base (rank l) plus one 32-bit byte offset per lane (the list), so the 3 LT accesses of a
+  // list share one address register (B <= 2^30, checked by the launcher).
+  auto at = [](const float* row, unsigned int off) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + off); };
+  auto at_w = [](float* row, unsigned int off) { return reinterpret_cast<float*>(reinterpret_cast<char*>(row) + off); };
+#pragma unroll 1
+  for (unsigned int b = bid * kLossThreads + tid; b < (unsigned int)B; b += nb * kLossThreads) {
+    const unsigned int off = b * 4u;
+    float o[LT], c[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {  // every load of the list up front: one round trip
+      o[l] = *at(scores + (long long)l * B, off);
+      c[l] = *at(clicks + (long long)l * B, off);
+    }
+    float m = o[0];
+#pragma unroll
+    for (int l = 1; l < LT; ++l) m = fmaxf(m, o[l]);
+    float ex[LT], se = 0.f, S = 0.f, lw = 0.f;
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      ex[l] = fast_exp(o[l] - m);
+      se += ex[l];
+      S += (c[l] + 0.0000001f) * pw[l];
+      lw += pw[l] * fminf(fmaxf(c[l], 0.f), 1.f);
+    }
+    const float rse = fast_rcp(se), lse = m + fast_log(se);
+    const float p0 = ex[0] * rse;
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      const float sm = ex[l] * rse;
+      const float rw = clip_w(p0 * fast_rcp(sm), max_pw);  // relevance weights (dla.py:159-160)
+      rws[l] += rw;
+      const float wl = (c[l] + 0.0000001f) * pw[l];
+      rank_num += -wl * (o[l] - lse);
+      const float wle = (c[l] + 0.0000001f) * rw;
+      exam_num += -wle * s_tower[2 * 16 + l];
+      exam_den += wle;
+      col[l] += wle;
+      *at_w(a.d_scores + (long long)l * B, off) = sm * S - wl;
+    }
+    rank_den += S;
+    if (a.list_weights) a.list_weights[b] = lw / (float)LT;
+  }
+  float* mine = s_part + wid * kMaxStat;
+  rank_num = wave_sum(rank_num);
+  rank_den = wave_sum(rank_den);
+  exam_num = wave_sum(exam_num);
+  exam_den = wave_sum(exam_den);
+  if (lane == 0) {
+    mine[0] = rank_num;
+    mine[1] = rank_den;
+    mine[2] = exam_num;
+    mine[3] = exam_den;
+  }
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    const float r = wave_sum(rws[l]), cl = wave_sum(col[l]);
+    if (lane == 0) {
+      mine[4 + l] = 0.f;  // pw_l is batch independent: written once by the last block
+      mine[4 + LT + l] = r;
+      mine[4 + 2 * LT + l] = cl;
     }
   }
+  dla_stats_tail(a, bid, nb, s_acc, s_part, s_tower);
 }
 
 // ------------------------------------------------------------------------------------------
