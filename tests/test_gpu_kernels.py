@@ -511,6 +511,15 @@ def test_metrics_kernel(L, B, Lx):
     M.batch_metrics(plan2, dev(s32.T), dev(labels2.T, torch.float32), None, 0, None, out2, keep(M.metrics_workspace(B, plan2, 'cuda')),
                     dev(u), max_label=2.0)
     assert abs(out2[0].item() - O.ndcg(labels2, s32.astype(np.float64), None, 5, u, u)) < 2e-6
+    # no tie-break uniforms at all: equal scores keep their index order
+    plan3 = M.MetricPlan(['mrr', 'ndcg'], [3, 10])
+    out3 = torch.zeros(plan3.n_out, dtype=torch.float32, device='cuda')
+    M.batch_metrics(plan3, dev(s32.T), dev(labels.T, torch.float32), None, 0, None, out3, keep(M.metrics_workspace(B, plan3, 'cuda')),
+                    None, max_label=2.0)
+    got3 = out3.cpu().numpy().astype(np.float64)
+    assert abs(got3[plan3.slot('ndcg', 1, False)] - O.ndcg(labels, s32.astype(np.float64), None, 10)) < 2e-6
+    assert abs(got3[plan3.slot('ndcg', 0, False)] - O.ndcg(labels, s32.astype(np.float64), None, 3)) < 2e-6
+    assert abs(got3[plan3.slot('mrr', 0, False)] - O.mrr(labels, s32.astype(np.float64), None)) < 2e-6
     # the factory API of the reference (metrics.py:64)
     fn = M.make_ranking_metric_fn('ndcg', 3)
     v = fn(dev(labels, torch.float32), dev(s32), None)

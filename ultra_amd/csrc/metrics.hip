@@ -204,9 +204,12 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(MetricsArgs a) {
 // 128-byte line per load), a list's scores / labels / uniforms live in registers, and the positions come from
 // rank-by-counting over the list's pairs -- no lane ever talks to another before the final sums.
 constexpr int kLanesMinB = 32768, kLanesMaxBlocks = 2048;
-template <int LM, bool WANT_ERR>
+// HAS_U: tie-break uniforms exist (supplied or drawn); without them ties fall to the lower index and no uniform is held.
+template <int LM, bool WANT_ERR, bool HAS_U>
 __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs a) {
   __shared__ float s_vals[4 * kMaxOut];
+  __shared__ float s_log[LM];  // log(rank + 2), the discount's denominator: one table instead of 2 Lx logarithms a list
+  if (threadIdx.x < LM) s_log[threadIdx.x] = logf((float)threadIdx.x + 2.f);
   const float* __restrict__ scores = a.scores; const float* __restrict__ labels = a.labels;
   const int* __restrict__ docids = a.docids; const float* __restrict__ list_weights = a.list_weights;
   const float* __restrict__ u_pred = a.u_pred;
@@ -224,6 +227,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
   const unsigned int t_step = draw_ties ? tie_step_of(a) : 0u;
   float* my_row = s_vals + (tid >> 6) * nout;
   if ((tid & 63) < nout) my_row[tid & 63] = 0.f;
+  __syncthreads();
   for (long long b0 = (long long)blockIdx.x * kMetThreads; b0 < B; b0 += (long long)gridDim.x * kMetThreads) {
     const bool on = b0 + tid < B;
     const long long b = on ? b0 + tid : B - 1;  // idle lanes redo the last list and contribute nothing
@@ -236,8 +240,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
         s[l] = scores[g];
         if (docids && docids[g] == n_rows) s[l] = kPaddingScore;
         lab[l] = labels[g];
-        if (u_pred) u[l] = u_pred[b * Lx + l];
-        else if (draw_ties) u[l] = tie_uniform(a, t_step, b, l);
+        if (HAS_U) u[l] = u_pred ? u_pred[b * Lx + l] : tie_uniform(a, t_step, b, l);
       }
     }
     const float w = list_weights ? list_weights[b] : 1.f;
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
       if (i < Lx) {
 #pragma unroll
         for (int j = 0; j < i; ++j) {
-          const bool jb = s[j] > s[i] || (s[j] == s[i] && u[j] <= u[i]);
+          const bool jb = s[j] > s[i] || (s[j] == s[i] && (!HAS_U || u[j] <= u[i]));
           rank[i] += jb ? 1 : 0;
           rank[j] += jb ? 0 : 1;
           if (want_ndcg) {
@@ -285,6 +288,9 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
           }
         }
       }
+      // one row of pairs at a time: left alone the scheduler hoists every comparison of the list to the front, and the
+      // ~100 lane masks they produce spill from the scalar registers (measured: 2500 readlane / writelane per list walk)
+      __builtin_amdgcn_sched_barrier(0);
     }
     float mrr = 0.f, rel_sum = 0.f, dcg[kMaxTopn], idcg[kMaxTopn], err[kMaxTopn];
 #pragma unroll
@@ -295,7 +301,7 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
         const float gain = exp2f(lab[l]) - 1.f;
         rel_sum += gain;
         if (lab[l] >= 1.f) mrr = fmaxf(mrr, 1.f / (float)(rank[l] + 1));
-        const float gd = gain / logf((float)rank[l] + 2.f), igd = gain / logf((float)irank[l] + 2.f);
+        const float gd = gain / s_log[rank[l]], igd = gain / s_log[irank[l]];
         // cumprod(1 - rel) / (1 - rel) as the reference writes it (metrics.py:312-314)
         const float e_term = want_err ? (1.f - omr[l]) * ((above[l] * omr[l]) / omr[l]) / (float)(rank[l] + 1) : 0.f;
 #pragma unroll
@@ -310,29 +316,36 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
       }
     }
     const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
-    const int mi_ndcg = want_mrr ? 1 : 0, mi_err = mi_ndcg + (want_ndcg ? 1 : 0);
+    // outputs in the order [metric][topn][plain, weighted]: the slot index is a running (uniform) count, the per-topn
+    // sums are indexed statically
+    int o = 0;
+    auto emit = [&](float plain, float weighted) {
+      const float v0 = wave_sum(on ? plain : 0.f), v1 = wave_sum(on ? weighted : 0.f);
+      if ((tid & 63) == 0) {
+        my_row[o] += v0;
+        my_row[o + 1] += v1;
+      }
+      o += 2;
+    };
+    if (want_mrr) {
 #pragma unroll
-    for (int o = 0; o < kMaxOut; ++o) {
-      if (o < nout) {
-        const int weighted = o & 1, q = (o >> 1) % n_topn, mi = (o >> 1) / n_topn;
-        float d = 0.f, idn = 0.f, er = 0.f;
+      for (int q = 0; q < kMaxTopn; ++q)
+        if (q < n_topn) emit(mrr, mrr * w);
+    }
+    if (want_ndcg) {
 #pragma unroll
-        for (int qq = 0; qq < kMaxTopn; ++qq)
-          if (qq == q) { d = dcg[qq]; idn = idcg[qq]; er = err[qq]; }
-        float val;
-        if (want_mrr && mi == 0) {
-          val = weighted ? mrr * w : mrr;
-        } else if (want_ndcg && mi == mi_ndcg) {
+      for (int q = 0; q < kMaxTopn; ++q)
+        if (q < n_topn) {
+          const float d = dcg[q], idn = idcg[q];
           const float nd = idn != 0.f ? d / idn : 0.f;
           const float ndw = (w * idn) != 0.f ? (w * d) / (w * idn) : 0.f;
-          val = weighted ? ndw * plw_w : nd * plw_plain;
-        } else {
-          (void)mi_err;
-          val = weighted ? er * w : er;
+          emit(nd * plw_plain, ndw * plw_w);
         }
-        const float v = wave_sum(on ? val : 0.f);
-        if ((tid & 63) == 0) my_row[o] += v;
-      }
+    }
+    if (want_err) {
+#pragma unroll
+      for (int q = 0; q < kMaxTopn; ++q)
+        if (q < n_topn) emit(err[q], err[q] * w);
     }
   }
   __syncthreads();
@@ -392,11 +405,19 @@ int launch_metrics_now(const MetricsArgs& a, unsigned nblocks, hipStream_t st) {
   }
   if (a.P <= 16 && a.B >= kLanesMinB) {  // one lane per list (nblocks was sized for it by prepare_metrics)
     ultr::ProfScope prof_("metrics_lanes_kernel", st);
-    const bool err = (a.metric_mask & ULTR_METRIC_ERR) != 0;
-    if (a.Lx <= 8 && err) hipLaunchKernelGGL((metrics_lanes_kernel<8, true>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
-    else if (a.Lx <= 8) hipLaunchKernelGGL((metrics_lanes_kernel<8, false>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
-    else if (err) hipLaunchKernelGGL((metrics_lanes_kernel<16, true>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
-    else hipLaunchKernelGGL((metrics_lanes_kernel<16, false>), dim3(nblocks), dim3(kMetThreads), 0, st, a);
+    const bool err = (a.metric_mask & ULTR_METRIC_ERR) != 0, has_u = a.u_pred || a.tie_seed != 0ull;
+#define ULTR_LANES(LM, E, U) hipLaunchKernelGGL((metrics_lanes_kernel<LM, E, U>), dim3(nblocks), dim3(kMetThreads), 0, st, a)
+    if (a.Lx == 10) {  // the reference's rank_list_size: compiled for the exact length, no per-rank guards
+      if (err) { if (has_u) ULTR_LANES(10, true, true); else ULTR_LANES(10, true, false); }
+      else { if (has_u) ULTR_LANES(10, false, true); else ULTR_LANES(10, false, false); }
+    } else if (a.Lx <= 8) {
+      if (err) { if (has_u) ULTR_LANES(8, true, true); else ULTR_LANES(8, true, false); }
+      else { if (has_u) ULTR_LANES(8, false, true); else ULTR_LANES(8, false, false); }
+    } else {
+      if (err) { if (has_u) ULTR_LANES(16, true, true); else ULTR_LANES(16, true, false); }
+      else { if (has_u) ULTR_LANES(16, false, true); else ULTR_LANES(16, false, false); }
+    }
+#undef ULTR_LANES
     return check_launch("metrics_lanes_kernel");
   }
   {
