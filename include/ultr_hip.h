@@ -388,6 +388,13 @@ int ultr_pd_update_ratios_deferred(float* t_plus, float* t_minus, int L, float* 
                                    float regulation_p, float* old_out, void* stream);
 int ultr_em_update_flush(void* stream);
 
+/* The fused training step (ultr_dnn_train_fused) carries a parked metric evaluation as rider workgroups that stop at
+ * their partial rows; the column sums, the division by B and the tie counter's bump are parked on the calling thread
+ * for the next ultr_clip_adagrad* call, whose update launch performs them before it publishes (a parameter group of
+ * <= 4096 floats: a one-workgroup launch first).  The metric outputs are therefore valid after that call, or after
+ * ultr_metrics_tail_flush, which performs a parked reduction on `stream` at once (no-op when nothing is parked). */
+int ultr_metrics_tail_flush(void* stream);
+
 /* ---- metrics (metrics.py:215-323,445-481; sort metric_utils.py:49-86) --------------------
  * scores/labels [Lx][B] position-major.  docids (may be NULL) [Lx][B]: entries == n_rows get
  * PADDING_SCORE first (base_algorithm.py:64-87).  list_weights [B] or NULL (per-list weights).

@@ -100,6 +100,7 @@ SIGNATURES = {
     'ultr_rem_update_propensity_deferred': (_I, [_P, _I, _P, _F, _P, _P]),
     'ultr_pd_update_ratios_deferred': (_I, [_P, _P, _I, _P, _F, _F, _P, _P]),
     'ultr_em_update_flush': (_I, [_P]),
+    'ultr_metrics_tail_flush': (_I, [_P]),
     'ultr_metrics_workspace_floats': (_LL, [_I, _I]),
     'ultr_metrics': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
     'ultr_metrics_static_max_floats': (_LL, []),

@@ -1401,6 +1401,16 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   if (g_pending_metrics.on) {
     fr.m = g_pending_metrics.a; fr.m_blocks = (int)g_pending_metrics.nblocks; fr.m_pad = (fr.m_blocks + 7) & ~7;
     g_pending_metrics.on = false;
+    // the rider leaves partial rows; the update launch (ultr_clip_adagrad*), next on this stream, adds them up
+    rc = ultr_metrics_tail_flush(st);  // an earlier one nobody carried
+    if (rc) return rc;
+    const MetricsArgs& m = fr.m;
+    const int n_met = ((m.metric_mask & ULTR_METRIC_MRR) ? 1 : 0) + ((m.metric_mask & ULTR_METRIC_NDCG) ? 1 : 0) +
+                      ((m.metric_mask & ULTR_METRIC_ERR) ? 1 : 0);
+    fr.m.defer_reduce = 1;
+    g_pending_mtail.on = true;
+    g_pending_mtail.t = MetricsTail{m.ws + 8, fr.m_blocks, n_met * m.n_topn * 2, m.B, m.list_weights ? 1 : 0, m.out,
+                                    (m.tie_ctr && !m.u_pred && m.tie_seed != 0ull) ? m.tie_ctr : nullptr};
   }
   fr.ride = pl.kind; fr.dla = pl.dla; fr.ipw = pl.ipw; fr.rem = pl.rem; fr.pd = pl.pd;
   // the chain kernel has written the list weights: the loss rider must not race with the metrics that read them

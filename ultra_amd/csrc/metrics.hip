@@ -390,6 +390,20 @@ extern "C" long long ultr_metrics_workspace_floats(int B, int n_topn) {
 
 namespace ultr {
 thread_local PendingMetrics g_pending_metrics = {};
+thread_local PendingMetricsTail g_pending_mtail = {};
+
+__global__ void __launch_bounds__(kMetThreads) metrics_tail_kernel(MetricsTail t) {
+  __shared__ float s_tmp[kMetThreads];
+  __shared__ float s_acc[kMaxOut];
+  metrics_tail_body(t, s_tmp, s_acc);
+}
+int launch_metrics_tail_now(const MetricsTail& t, hipStream_t st) {
+  {
+    ultr::ProfScope prof_("metrics_tail_kernel", st);
+    hipLaunchKernelGGL(metrics_tail_kernel, dim3(1), dim3(kMetThreads), 0, st, t);
+  }
+  return check_launch("metrics_tail_kernel");
+}
 
 static size_t metrics_smem(const MetricsArgs& a) {
   const int n_met = ((a.metric_mask & 1) ? 1 : 0) + ((a.metric_mask & 2) ? 1 : 0) + ((a.metric_mask & 4) ? 1 : 0);
@@ -468,6 +482,12 @@ extern "C" int ultr_metrics(const float* scores, const float* labels, const int*
                                  n_topn, metric_mask, max_label, out, ws, &a, &nblocks);
   if (rc) return rc;
   return launch_metrics_now(a, nblocks, as_stream(stream));
+}
+
+extern "C" int ultr_metrics_tail_flush(void* stream) {
+  if (!g_pending_mtail.on) return ULTR_OK;
+  g_pending_mtail.on = false;
+  return launch_metrics_tail_now(g_pending_mtail.t, as_stream(stream));
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------------------------------

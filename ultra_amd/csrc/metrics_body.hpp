@@ -26,7 +26,27 @@ struct MetricsArgs {
   // tie_step + *tie_ctr), key = tie_seed; the last workgroup of the launch bumps *tie_ctr, so the next call -- or the
   // next replay of a captured graph -- draws new ones
   unsigned long long tie_seed; unsigned int tie_step; unsigned int* tie_ctr; unsigned int tie_slot_base;
+  // != 0 (the fused training step only): the workgroups leave their partial rows in ws and stop; the optimiser's update
+  // launch, which comes next on the stream, adds them up (MetricsTail).  Takes the arrival counter, the wait for it and
+  // the reload of the rows -- about 4 us of dependent memory round trips -- off the launch that carries this rider.
+  int defer_reduce;
 };
+
+// The deferred last step of a metric evaluation: rows [nb][nout] -> out[nout] = column sums / B, in the order the last
+// workgroup of metrics_finish uses (same reduce_rows walk, same block size), and the tie counter's bump.
+struct MetricsTail {
+  const float* rows; int nb, nout, B, weighted;
+  float* out; unsigned int* tie_ctr;
+};
+__device__ __forceinline__ void metrics_tail_body(const MetricsTail& t, float* s_tmp, float* s_acc) {
+  reduce_rows<false>(t.rows, t.nb, t.nout, 1 << 30, s_tmp, s_acc);
+  const int tid = threadIdx.x;
+  if (tid < t.nout && ((tid & 1) == 0 || t.weighted)) t.out[tid] = s_acc[tid] / (float)t.B;
+  if (tid == 0 && t.tie_ctr) __hip_atomic_fetch_add(t.tie_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct PendingMetricsTail { bool on; MetricsTail t; };
+extern thread_local PendingMetricsTail g_pending_mtail;
+int launch_metrics_tail_now(const MetricsTail& t, hipStream_t st);  // metrics.hip
 
 __device__ __forceinline__ unsigned int tie_step_of(const MetricsArgs& a) {
   return a.tie_step + (a.tie_ctr ? __hip_atomic_load(a.tie_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
@@ -221,6 +241,10 @@ __device__ __forceinline__ void metrics_finish(const MetricsArgs& a, int bid, in
   unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
   float* rows = ws + 8;
   __syncthreads();
+  if (a.defer_reduce) {  // the next launch on the stream adds the rows
+    if (tid < nout) rows[(long long)bid * nout + tid] = s_acc[tid];
+    return;
+  }
   // hand-off without cache maintenance: agent-scope stores and loads around an atomic arrival counter (loss_body.hpp)
   if (tid < nout) st_agent(rows + (long long)bid * nout + tid, s_acc[tid]);
   if (last_block_arrive_sc1(counter, nb)) {

@@ -95,6 +95,13 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
     if (threadIdx.x == 0 && idx >= 0 && idx < o.pub_n) o.pub_dst[idx] = rider.out_norm[0];
     return;
   }
+  if (bid == 0 && o.mt.nb > 0) {  // the in-step metrics: partial rows of the launch before -> the values published below
+    __shared__ float s_mt_tmp[kOptThreads];
+    __shared__ float s_mt_acc[kMaxOut];
+    metrics_tail_body(o.mt, s_mt_tmp, s_mt_acc);
+    __threadfence_block();
+    __syncthreads();
+  }
   if (bid == 0 && o.em.kind != 0) {  // a handful of floats of EM state; its outputs are part of the row published below
     if (o.em.kind == ULTR_RIDE_REM) rem_update_body(o.em);
     else pd_update_body(o.em);
@@ -209,6 +216,15 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
   ULTR_REQUIRE(strategy == ULTR_OPT_ADAGRAD || strategy == ULTR_OPT_SGD, ULTR_EINVAL,
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
+  if (g_pending_mtail.on) {  // the column sums of the fused step's in-step metrics: carried likewise
+    g_pending_mtail.on = false;
+    if (n > 4096) {
+      o.mt = g_pending_mtail.t;
+    } else {
+      const int rc = launch_metrics_tail_now(g_pending_mtail.t, as_stream(stream));
+      if (rc) return rc;
+    }
+  }
   if (g_pending_em.on) {  // a parked EM-state update: carried by the big update launch, else a launch of its own now
     g_pending_em.on = false;
     if (n > 4096) {

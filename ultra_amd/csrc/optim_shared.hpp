@@ -2,6 +2,7 @@
 #pragma once
 #include "feed_body.hpp"
 #include "loss_body.hpp"
+#include "metrics_body.hpp"
 
 namespace ultr {
 
@@ -55,6 +56,9 @@ struct TailOpts {
   AssembleArgs a; int a_blocks, a_pad;
   // em.kind != 0: the EM-state update of regression-EM / pairwise debiasing, run by workgroup 0 before it publishes
   EmUpdate em;
+  // mt.nb > 0: the column sums of a metric evaluation whose rider workgroups left only partial rows (the fused step's
+  // slab-reduction launch), formed by workgroup 0 before it publishes
+  MetricsTail mt;
 };
 
 int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom, float scale_const,

@@ -412,6 +412,10 @@ class BaseAlgorithm(ABC):
             self.model.train_fused(batch.table, batch.table_stats, batch.n_rows, batch.docids[:self.rank_list_size],
                                    scores, tb['grads'], tb['sumsq'] if tb['sumsq_valid'] else None)
             _lib.check(lib.ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
+            if self.world > 1:
+                # the fused step leaves the metrics' column sums to the update launch; the collective in between reads
+                # them, so with several ranks they are formed now
+                _lib.check(lib.ultr_metrics_tail_flush(_lib.current_stream()), 'ultr_metrics_tail_flush')
             self._after_scores(tb, batch, scores)
         except Exception:
             lib.ultr_metrics_cancel()                          # the scores these requests describe never came to be
@@ -449,6 +453,7 @@ class BaseAlgorithm(ABC):
         tb, batch = self._pending
         self._tail = self._arm_tail(tb)                        # consumed by the (last) clip + optimiser call of _update
         self._update(tb, batch)                                # EM state, clip + Adagrad
+        _lib.check(_lib.lib().ultr_metrics_tail_flush(_lib.current_stream()), 'ultr_metrics_tail_flush')  # no-op if carried
         fetch = self._publish(tb, copied=self._tail is not None and self._tail.get('published', False))
         self._tail = None
         self.global_step.value += 1
