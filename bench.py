@@ -207,6 +207,9 @@ def main():
                     help='0: eager launches; 1: the whole step as one hipGraph (single GPU only); 2: two hipGraphs '
                          '(before / after the collective) with the RCCL all-reduce issued between them.  Default: 1 on '
                          'one GPU, 2 on several')
+    ap.add_argument('--graph_steps', type=int, default=0,
+                    help='--graph 1 only: consecutive steps captured into one hipGraph (--steps must be a multiple); '
+                         '0 = 4, or the largest of 4 / 2 / 1 that divides --steps')
     ap.add_argument('--force_collective', action='store_true',
                     help='single-GPU rehearsal of the multi-GPU launch path: a 1-rank RCCL group, all-reduce issued anyway')
     ap.add_argument('--algo_hparams', default='')
@@ -248,6 +251,8 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):  # the plugin classes print progress lines like the reference does
         data, exp, model, feed = build_world(cfg, args, device)
     use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 2)
+    if args.graph_steps <= 0:
+        args.graph_steps = next(k for k in (4, 2, 1) if args.steps % k == 0)
     if use_graph == 1 and (world > 1 or args.force_collective):
         use_graph = 2  # the collective is never captured
 
@@ -280,15 +285,23 @@ def main():
     # few steps and the timed region uses the faster one; "launch" in the output names it.
     paths = {'eager': step}
     last_of = {}
+    steps_per_call = {}
     if use_graph:
         try:
             model.enable_graph_replay(True)
             step()
             torch.cuda.synchronize()
             if use_graph == 1:
+                # --graph_steps consecutive steps per graph: kernels inside a graph run back to back, while two replays
+                # are a few microseconds apart.  Every captured step publishes into its own pinned ring slot, so
+                # each step's loss and summary stay readable after a replay.
+                if args.graph_steps > 1:
+                    model.enable_graph_replay(False)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    last_of['hipGraph replay'] = step()
+                    for _ in range(args.graph_steps):
+                        last_of['hipGraph replay'] = step()
+                steps_per_call['hipGraph replay'] = args.graph_steps
                 paths['hipGraph replay'] = graph.replay
             else:
                 # feed + forward + loss + metrics + backward | all-reduce (eager, RCCL's own stream) | update + publish
@@ -319,10 +332,11 @@ def main():
         for name, fn in paths.items():
             barrier()
             t0 = time.perf_counter()
-            for _ in range(30):
+            for _ in range(max(1, 32 // steps_per_call.get(name, 1))):
                 fn()
             torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            t = torch.tensor([(time.perf_counter() - t0) * 30.0 / (max(1, 32 // steps_per_call.get(name, 1)) * steps_per_call.get(name, 1))],
+                             dtype=torch.float64, device=device)
             if world > 1:
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)  # every rank picks the same path
             trial[name] = float(t.item())
@@ -330,9 +344,12 @@ def main():
         launch = min(trial, key=trial.get)
     run = paths[launch]
 
+    spc = steps_per_call.get(launch, 1)
+    if args.steps % spc:
+        raise SystemExit('--steps %d is not a multiple of --graph_steps %d' % (args.steps, spc))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // spc):                     # exactly args.steps steps
         r = run()
     barrier()
     dt = time.perf_counter() - t0
@@ -400,7 +417,7 @@ def main():
                                    args.config, cfg['F'], cfg['L'], args.batch, cfg['algo'],
                                    'PBM' if 'pbm' in cfg['click'] else 'cascade', cfg['Q'], 'toy-data' if cfg.get('data_dir') else 'synthetic'),
                    'global_batch': args.batch * world, 'list_size': cfg['L'], 'parallelism': 'dp%d' % world,
-                   'launch': launch, 'feed_prefetch': bool(args.prefetch),
+                   'launch': launch, 'steps_per_graph': spc, 'feed_prefetch': bool(args.prefetch),
                    'train_gflop_per_step_per_gpu': round(train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9, 3)},
         'final_loss': loss_value,
     }
