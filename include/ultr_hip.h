@@ -18,7 +18,10 @@
  *     (workspaces) and are re-entrant per stream.  Three families do keep state, all of it on the
  *     host side of the library:
  *       (1) the *_deferred calls (ultr_loss_*_deferred, ultr_metrics_deferred,
- *           ultr_batch_assemble_deferred) PARK one request per kind PER HOST THREAD (thread_local):
+ *           ultr_batch_assemble_deferred, ultr_rem_update_propensity_deferred,
+ *           ultr_pd_update_ratios_deferred -- and ultr_dnn_train_fused itself, which parks the last
+ *           step of a metric evaluation it carried for the next ultr_clip_adagrad* call, see
+ *           ultr_metrics_tail_flush) PARK one request per kind PER HOST THREAD (thread_local):
  *           nothing is launched; a later carrying call made BY THE SAME THREAD (ultr_dnn_backward*,
  *           ultr_dnn_train_fused, ultr_clip_adagrad_fused; each request's comment names its carriers)
  *           launches the parked work inside one of its own launches, on the CARRIER's stream.
