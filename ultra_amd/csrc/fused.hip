@@ -1418,12 +1418,9 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   fr.l_blocks = (int)pl.nblocks; fr.l_pad = (fr.l_blocks + 7) & ~7;
   // (a parked batch assembly stays parked: it rides with the update launch, ultr_clip_adagrad_fused -- this launch's
   // riders still read the current batch, which the assembly overwrites)
-  static const int k3skip = [] { const char* e = getenv("ULTR_K3_SKIP"); return e ? atoi(e) : 0; }();  // DIAG
-  if (k3skip & 1) fr.l_blocks = 0;
-  if (k3skip & 2) fr.m_blocks = 0;
   {
     ultr::ProfScope prof_("finalize_fused_kernel", st);
-    hipLaunchKernelGGL(finalize_fused_kernel, dim3(((k3skip & 4) ? 1 : fblocks) + (unsigned)(fr.m_pad + fr.l_pad)), dim3(kThreads), 0, st, fr);
+    hipLaunchKernelGGL(finalize_fused_kernel, dim3(fblocks + (unsigned)(fr.m_pad + fr.l_pad)), dim3(kThreads), 0, st, fr);
   }
   return check_launch("finalize_fused_kernel");
 }
