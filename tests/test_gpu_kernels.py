@@ -1013,6 +1013,41 @@ def test_online_kernels_short_and_long_list_layouts_agree(L, model_file, stochas
     assert (outs[0][1][:Ls].sum(0)[shown] >= 1).all()
 
 
+@pytest.mark.parametrize('model_file,stochastic,Lmax', [('pbm_0.1_1.0_4_1.0.json', False, 10), ('ubm_0.1_1_4_1.0.json', False, 16),
+                                                        ('cascade_0.1_1.0_4_1.0.json', True, 10),
+                                                        ('cascade_0.1_1.0_4_1.0.json', False, 13)])
+def test_online_kernel_many_lists_layout_agrees(L, model_file, stochastic, Lmax):
+    """From 131072 lists of at most 16 candidates on a lane owns a whole list.  The same lists padded to 17 columns go
+    through the workgroup-per-list kernel and must come out identical: ranking, Plackett-Luce noise, every re-sampling
+    round of the clicks."""
+    model = load_json(model_file)
+    rng = np.random.RandomState(Lmax)
+    B, wide, Ls, n_rows = 140001, 17, 10, 4000
+    lens = rng.randint(0, Lmax + 1, size=B)
+    docids = np.full((B, wide), n_rows, dtype=np.int32)
+    labels = np.zeros((B, wide), dtype=np.float32)
+    live = np.arange(wide)[None, :] < lens[:, None]
+    docids[live] = rng.randint(0, n_rows, size=int(live.sum()))
+    labels[live] = rng.choice(5, size=int(live.sum()))
+    docids[::7, 1] = n_rows                       # holes inside a list: the length is 1 + the last real position
+    scores = np.round(rng.normal(size=(B, wide)), 1).astype(np.float32)
+    kind, exam, n_exam, cp = _device_click_model(model, Ls)
+    outs = []
+    for width in (Lmax, wide):
+        o = [torch.full((width, B), -5, dtype=t, device='cuda') for t in (torch.int32, torch.float32, torch.int32)]
+        args = (L.ptr(dev(docids[:, :width].T)), L.ptr(dev(labels[:, :width].T)), L.ptr(dev(scores[:, :width].T)), B, width,
+                min(Ls, Lmax), n_rows, kind, L.ptr(exam), n_exam, L.ptr(cp), cp.numel(), None, 777, 5, None, 2000, 1, 100,
+                L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), stream(L))
+        if stochastic:
+            L.check(L.lib().ultr_online_sample_click(1.5, None, *args), 'online')
+        else:
+            L.check(L.lib().ultr_online_rerank_click(*args), 'online')
+        outs.append([t.cpu().numpy()[:Lmax] for t in o])
+    for a, b, name in zip(outs[0], outs[1], ('docids', 'clicks', 'order')):
+        assert np.array_equal(a, b), name
+    assert (outs[0][0] != -5).all() and (outs[0][1] != -5).all()
+
+
 @pytest.mark.parametrize('B,Lx', [(200, 10), (40000, 10), (25, 40)])  # 16 lanes per list, one lane per list, LDS bitonic sort
 def test_metrics_kernel_draws_its_own_tie_break_uniforms(L, B, Lx):
     """ultr_metrics_ties: ties between equal scores are broken by Philox uniforms drawn inside the kernel (the reference

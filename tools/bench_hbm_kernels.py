@@ -56,7 +56,7 @@ def main():
     exam = torch.tensor(g['exam_prob'], dtype=torch.float64, device=dev)
     cp = torch.tensor(g['click_prob'], dtype=torch.float64, device=dev)
     print('# kernel                   units               bytes       time       achieved   fraction  (event-timed, back to back)')
-    for logB in (12, 16, 20):
+    for logB in (12, 16, 18, 20):
         B = 1 << logB
         labels = torch.randint(0, 5, (B, Ls), device=dev).float()
         clicks = torch.empty_like(labels)

@@ -1,6 +1,7 @@
 // Click simulation and batch assembly on the device.
 // Reference: ultra/utils/click_models.py:86-116 (PBM), :204-241 (cascade);
 //            ultra/input_layer/click_simulation_feed.py:75-162 (get_batch).
+#include <type_traits>
 #include "feed_body.hpp"
 
 namespace ultr {
@@ -464,6 +465,122 @@ __global__ void __launch_bounds__(256) online_rerank_click_small_kernel(OnlineAr
   if (has_pos) a.out_clicks[e] = r < len ? click : lab;  // ranks beyond the shown ones are 0, padding keeps its label
 }
 
+// Very many short lists (exactly LT <= 16 positions, Philox draws): one lane per LIST.  The position-major arrays make
+// every load and store a full row per wave; ranks come from counting over the list's pairs in registers, the click model
+// walks the ranks in order (so the user browsing model needs no ballots), and every lane re-samples its own list until
+// it has a click.  Same keys, draws and thresholds as the two kernels above: identical outputs.
+// STOCH: Plackett-Luce keys (float64 Gumbel noise on tau * score); otherwise the scores themselves order the list (a
+// float compares like its float64 image).
+constexpr int kOnlineListsMinB = 131072;  // below, the 16-lane kernel wins: re-sampling rounds diverge less over 4 lists than over 64
+template <int LT, bool STOCH>
+__global__ void __launch_bounds__(256) online_rerank_click_lists_kernel(OnlineArgs a) {
+  typedef typename std::conditional<STOCH, double, float>::type key_t;
+  const int B = a.B;
+  const unsigned int step = a.step + (a.step_ctr ? *a.step_ctr : 0u);
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  const int rounds = 1 + (a.check_validation ? a.max_rounds : 0);
+#pragma unroll 1
+  for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long long)gridDim.x * 256) {
+    const uint32_t slot = a.slot_base + (uint32_t)b;
+    int doc[LT];
+    float lab[LT];
+    key_t key[LT];
+#pragma unroll
+    for (int p = 0; p < LT; ++p) {
+      const long long e = (long long)p * B + b;
+      doc[p] = a.docids[e];
+      lab[p] = a.labels[e];
+      key[p] = (key_t)a.scores[e];
+    }
+    if (STOCH) {
+      Philox4 bd{};
+#pragma unroll
+      for (int p = 0; p < LT; ++p) {
+        if ((p & 1) == 0) bd = philox4x32_10(slot, 0xFFFFFFFFu, (uint32_t)(p >> 1), step, k0, k1);
+        double u = (p & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
+        u = u > 8.673617379884035e-19 ? u : 8.673617379884035e-19;  // 2^-60: keeps the noise finite
+        key[p] = (key_t)((double)a.tau * (double)key[p] - log(-log(u)));
+      }
+    }
+    int len = 0;
+#pragma unroll
+    for (int p = 0; p < LT; ++p) len = doc[p] < a.n_rows ? p + 1 : len;
+    // rank(p) = #{q < len : key_q > key_p or (key_q == key_p and q < p)}, for p < len
+    int rank[LT];
+#pragma unroll
+    for (int p = 0; p < LT; ++p) rank[p] = 0;
+#pragma unroll
+    for (int p = 1; p < LT; ++p) {
+#pragma unroll
+      for (int q = 0; q < p; ++q) {  // q < p: on equal keys q goes first
+        const bool both = p < len;  // q < p < len
+        rank[p] += (both && key[q] >= key[p]) ? 1 : 0;
+        rank[q] += (both && key[p] > key[q]) ? 1 : 0;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one row of pairs at a time (see metrics_lanes_kernel)
+    }
+    // the position that lands on rank r, its document and label
+    float rlab[LT];
+#pragma unroll
+    for (int r = 0; r < LT; ++r) {
+      int src = r, rd = doc[r];
+      float rl = lab[r];
+#pragma unroll
+      for (int p = 0; p < LT; ++p) {
+        const bool hit = r < len && p < len && rank[p] == r;
+        src = hit ? p : src;
+        rd = hit ? doc[p] : rd;
+        rl = hit ? lab[p] : rl;
+      }
+      rlab[r] = rl;
+      const long long e = (long long)r * B + b;
+      a.out_docids[e] = rd;
+      if (a.out_perm) a.out_perm[e] = src;
+    }
+    const int Lc = a.L < len ? a.L : len;
+    unsigned int mask = 0u;
+    if (a.click_model != ULTR_CLICK_ORACLE && Lc > 0) {  // (oracle mode: the labels themselves, written below)
+      // the thresholds of a list do not change between re-sampling rounds, unless they depend on the last click
+      const bool fixed_thr = a.click_model != ULTR_CLICK_UBM;
+      double thr[LT];
+#pragma unroll
+      for (int r = 0; r < LT; ++r) thr[r] = fixed_thr ? click_threshold(a.t, a.click_model, r, rlab[r], -1) : 0.0;
+      for (int round = 0; round < rounds; ++round) {
+        unsigned int m = 0u;
+        int last = -1;
+        bool has_click = false;
+        Philox4 bd{};
+#pragma unroll
+        for (int r = 0; r < LT; ++r) {
+          if ((r & 1) == 0) bd = philox4x32_10(slot, (uint32_t)round, (uint32_t)(r >> 1), step, k0, k1);
+          const double u = (r & 1) ? u53(bd.w2, bd.w3) : u53(bd.w0, bd.w1);
+          const bool c = r < Lc && u < (fixed_thr ? thr[r] : click_threshold(a.t, a.click_model, r, rlab[r], last));
+          if (c && !(a.click_model == ULTR_CLICK_CASCADE && has_click)) m |= 1u << r;
+          has_click = has_click || c;
+          if (c) last = r;
+        }
+        mask = m;
+        if (m != 0u || !a.check_validation) break;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LT; ++r) {
+      float click = ((mask >> r) & 1u) ? 1.f : 0.f;
+      if (a.click_model == ULTR_CLICK_ORACLE) click = r < Lc ? rlab[r] : 0.f;
+      a.out_clicks[(long long)r * B + b] = r < len ? click : lab[r];  // ranks beyond the shown ones are 0, padding keeps its label
+    }
+  }
+}
+template <int LT>
+static void launch_online_lists(const OnlineArgs& a, unsigned nb, hipStream_t st) {
+  if (a.Lmax == LT) {
+    if (a.stochastic) hipLaunchKernelGGL((online_rerank_click_lists_kernel<LT, true>), dim3(nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((online_rerank_click_lists_kernel<LT, false>), dim3(nb), dim3(256), 0, st, a);
+  } else if constexpr (LT > 1) {
+    launch_online_lists<LT - 1>(a, nb, st);
+  }
+}
+
 }  // namespace ultr
 
 using namespace ultr;
@@ -660,6 +777,12 @@ static int online_common(int stochastic, float tau, const double* rank_uniforms,
   a.check_validation = check_validation; a.max_rounds = max_rounds;
   a.out_docids = out_docids; a.out_clicks = out_clicks; a.out_perm = out_perm;
   a.stochastic = stochastic; a.tau = tau; a.rank_uniforms = rank_uniforms;
+  if (Lmax <= 16 && B >= kOnlineListsMinB && !uniforms && !rank_uniforms) {  // very many short lists: a lane per list
+    const unsigned nb = (unsigned)(cdiv(B, 256) < 8192 ? cdiv(B, 256) : 8192);
+    ultr::ProfScope prof_("online_rerank_click_kernel", as_stream(stream));
+    launch_online_lists<16>(a, nb, as_stream(stream));
+    return check_launch("online_rerank_click_lists_kernel");
+  }
   if (Lmax <= 16) {  // short lists: sixteen lanes per list
     ultr::ProfScope prof_("online_rerank_click_kernel", as_stream(stream));
     hipLaunchKernelGGL(online_rerank_click_small_kernel, dim3((unsigned)cdiv(B, 16)), dim3(256), 0, as_stream(stream), a);
