@@ -430,6 +430,8 @@ __global__ void __launch_bounds__(256) online_rerank_click_small_kernel(OnlineAr
     const int rounds = a.uniforms ? 1 : 1 + (a.check_validation ? a.max_rounds : 0);
     bool done = !in_batch || Lc == 0;
     unsigned int mask = 0u;
+    // the threshold of a (rank, label) does not change between re-sampling rounds, unless it depends on the last click
+    const double thr = a.click_model != ULTR_CLICK_UBM ? click_threshold(a.t, a.click_model, r, rlab, -1) : 0.0;
     for (int round = 0; round < rounds; ++round) {
       if (__ballot(!done) == 0ull) break;
       double u = 2.0;
@@ -451,7 +453,7 @@ __global__ void __launch_bounds__(256) online_rerank_click_small_kernel(OnlineAr
           c = c || cq;
         }
       } else {
-        c = live && !done && u < click_threshold(a.t, a.click_model, r, rlab, -1);
+        c = live && !done && u < thr;
       }
       unsigned int m = (unsigned int)((__ballot(c) >> gbase) & 0xFFFFull);
       if (a.click_model == ULTR_CLICK_CASCADE) m &= (~m + 1u);  // only the first click counts
