@@ -94,6 +94,37 @@ def test_fused_step_refuses_without_a_parked_loss():
         m.model.train_fused(table, stats, 8, docids, tb['scores'], tb['grads'])
 
 
+def test_fused_step_metric_sums_come_with_the_update_or_a_flush():
+    """The fused step's metric rider stops at its partial rows: the sums are formed by the next update launch, or by
+    ultr_metrics_tail_flush (what a data-parallel step does before its collective)."""
+    from ultra_amd import _lib
+    data = SyntheticData(200, 10, 24, seed=5, pad_frac=0.1)
+    exp = settings('DLA', '', 'hidden_layer_sizes=[64, 32]')
+    outs = []
+    for flush in (False, True):
+        m, feed = make('DLA', data, exp, 64)
+        m.metric_uniforms = torch.tensor(np.random.RandomState(1).uniform(size=(64, 10)).astype(np.float32)).cuda()
+        feed_dict, _ = feed.get_batch(data, check_validation=True)
+        m.step_local(feed_dict)
+        tb = m._train_bufs
+        assert tb['fused']
+        met = tb['bucket'][m.n_total + m.n_stats:m.n_total + m.n_stats + m.train_plan.n_out]
+        torch.cuda.synchronize()
+        assert float(met.abs().sum()) == 0.0          # first step: nothing has formed the sums yet
+        if flush:
+            _lib.check(_lib.lib().ultr_metrics_tail_flush(_lib.current_stream()), 'flush')
+            torch.cuda.synchronize()
+            early = met.cpu().numpy().copy()
+            assert early.max() > 0.0
+        _, _, summary = m.step_apply()
+        torch.cuda.synchronize()
+        late = met.cpu().numpy().copy()
+        if flush:
+            assert np.array_equal(early, late)         # the update launch had nothing left to add
+        outs.append((late, summary.as_dict()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
 def test_fused_not_supported_shapes_fall_back():
     data = SyntheticData(50, 20, 24, seed=1)
     exp = settings('DLA', Lmax=20, cutoff=20)
