@@ -66,13 +66,28 @@ __device__ __forceinline__ bool goes_before(float sa, float ua, int ia, float sb
   return ia < ib;
 }
 
+// The value held by lane ^ J inside a 16-lane row (J = 1, 2, 4, 8), at VALU speed: quad permutes for 1 and 2, a half-row
+// mirror followed by a quad reversal for 4 (i -> 7 - i -> i ^ 4 inside each half row), a row rotation by 8 for 8.
+template <int J>
+__device__ __forceinline__ int xor_lane_i(int v) {
+  if (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  if (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  if (J == 4) return __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);               // row_ror:8
+}
+template <int J> __device__ __forceinline__ float xor_lane_f(float v) { return __int_as_float(xor_lane_i<J>(__float_as_int(v))); }
+
 // Short lists: the workgroup `bid` of `nb` walks its groups of LPB lists and leaves one row of nout partial sums per
-// wave in s_vals [4][nout].
-__device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bid, int nb, float* s_vals) {
+// wave in s_vals [4][nout].  PT = 16: the common case (lists of 9 to 16) with everything about the group width known
+// at compile time -- the ten exchange steps of the sort are DPP moves instead of LDS-routed shuffles, the group sums
+// carry no width dispatch; PT = 0: any power of two up to 64, decided at run time.  Same arithmetic in the same order.
+template <int PT>
+__device__ __forceinline__ void metrics_short_lists_t(const MetricsArgs& a, int bid, int nb, float* s_vals) {
   const float* __restrict__ scores = a.scores; const float* __restrict__ labels = a.labels;
   const int* __restrict__ docids = a.docids; const float* __restrict__ list_weights = a.list_weights;
   const float* __restrict__ u_pred = a.u_pred;
-  const int n_rows = a.n_rows, B = a.B, Lx = a.Lx, P = a.P, LPB = a.LPB, n_topn = a.n_topn, metric_mask = a.metric_mask;
+  const int n_rows = a.n_rows, B = a.B, Lx = a.Lx, P = PT ? PT : a.P, LPB = PT ? kMetThreads / PT : a.LPB, n_topn = a.n_topn,
+            metric_mask = a.metric_mask;
   const float max_label = a.max_label;
   const int topn[kMaxTopn] = {a.topn[0], a.topn[1], a.topn[2], a.topn[3], a.topn[4], a.topn[5], a.topn[6], a.topn[7]};
   const int n_met = ((metric_mask & ULTR_METRIC_MRR) ? 1 : 0) + ((metric_mask & ULTR_METRIC_NDCG) ? 1 : 0) +
@@ -80,13 +95,14 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
   const int nout = n_met * n_topn * 2;
   const int tid = threadIdx.x;
   float r_lab = 0.f, r_ilab = 0.f, r_w = 1.f;
+  auto gmax = [&](float v) { return PT == 16 ? group_max<16>(v) : group_max_rt(v, P); };
   const bool draw_ties = !u_pred && a.tie_seed != 0ull;
   const unsigned int t_step = draw_ties ? tie_step_of(a) : 0u;
     // Short lists: a list is a group of P lanes inside one wave and never touches LDS.  The grid is capped
     // (kMetMaxBlocks): beyond that a block walks several groups of LPB lists and keeps its outputs in registers,
     // so the number of partial rows the last block has to add stays bounded.
     const int r = tid & (P - 1), li = tid / P;
-    constexpr int kAccSlots = kMaxOut / 2;  // outputs per lane: nout / P <= 48 / 2
+    constexpr int kAccSlots = PT == 16 ? kMaxOut / 16 : kMaxOut / 2;  // outputs per lane: nout / P
     float vacc[kAccSlots];
 #pragma unroll
     for (int j = 0; j < kAccSlots; ++j) vacc[j] = 0.f;
@@ -107,9 +123,9 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
       }
       // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
       const bool real = id < Lx;
-      const float any_invalid = group_max_rt((real && lb < 0.f) ? 1.f : 0.f, P);
+      const float any_invalid = gmax((real && lb < 0.f) ? 1.f : 0.f);
       if (any_invalid != 0.f) {
-        const float mn = -group_max_rt(real ? -s : -INFINITY, P);
+        const float mn = -gmax(real ? -s : -INFINITY);
         if (real && lb < 0.f) {
           lb = 0.f;
           s = mn - 1e-6f;
@@ -118,23 +134,32 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
       const float lab_orig = lb;  // label of the document at ORIGINAL position r
       float il = real ? lb : -INFINITY;
       const bool want_ideal = (metric_mask & ULTR_METRIC_NDCG) != 0;
-      for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          const float ps = __shfl_xor(s, j, 64), pu = __shfl_xor(uu, j, 64);
-          const int pi = __shfl_xor(id, j, 64);
-          const bool lower = (r & j) == 0, first_low = (r & k) == 0;
-          const bool want_first = lower == first_low;  // this lane keeps the element that goes first
-          const bool mine_first = goes_before(s, uu, id, ps, pu, pi, Lx);
-          if (mine_first != want_first) {
-            s = ps; uu = pu; id = pi;
-          }
-          if (want_ideal) {
-            const float pl = __shfl_xor(il, j, 64);
-            // descending labels; on equal values either copy is the same number
-            const bool keep = want_first ? (il >= pl) : (il <= pl);
-            if (!keep) il = pl;
-          }
+      // one compare-exchange step of the network: partner values in, this lane's element out
+      auto exchange = [&](int k, int j, float ps, float pu, int pi, float pl) {
+        const bool lower = (r & j) == 0, first_low = (r & k) == 0;
+        const bool want_first = lower == first_low;  // this lane keeps the element that goes first
+        const bool mine_first = goes_before(s, uu, id, ps, pu, pi, Lx);
+        if (mine_first != want_first) {
+          s = ps; uu = pu; id = pi;
         }
+        if (want_ideal) {
+          // descending labels; on equal values either copy is the same number
+          const bool keep = want_first ? (il >= pl) : (il <= pl);
+          if (!keep) il = pl;
+        }
+      };
+      if (PT == 16) {
+#define ULTR_BITONIC_STEP(K, J) exchange(K, J, xor_lane_f<J>(s), xor_lane_f<J>(uu), xor_lane_i<J>(id), want_ideal ? xor_lane_f<J>(il) : 0.f)
+        ULTR_BITONIC_STEP(2, 1);
+        ULTR_BITONIC_STEP(4, 2); ULTR_BITONIC_STEP(4, 1);
+        ULTR_BITONIC_STEP(8, 4); ULTR_BITONIC_STEP(8, 2); ULTR_BITONIC_STEP(8, 1);
+        ULTR_BITONIC_STEP(16, 8); ULTR_BITONIC_STEP(16, 4); ULTR_BITONIC_STEP(16, 2); ULTR_BITONIC_STEP(16, 1);
+#undef ULTR_BITONIC_STEP
+      } else {
+        for (int k = 2; k <= P; k <<= 1)
+          for (int j = k >> 1; j > 0; j >>= 1)
+            exchange(k, j, __shfl_xor(s, j, 64), __shfl_xor(uu, j, 64), __shfl_xor(id, j, 64),
+                     want_ideal ? __shfl_xor(il, j, 64) : 0.f);
       }
       // label of the document now ranked r: fetch it from the lane of its original position
       const int src_lane = (tid & 63) - r + min(id, P - 1);
@@ -149,10 +174,10 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
       const float gain = live ? exp2f(lbr) - 1.f : 0.f, igain = live ? exp2f(ilr) - 1.f : 0.f;
       const float disc = logf((float)r + 2.f);
       const float gd = gain / disc, igd = igain / disc;
-      auto gsum = [&](float v) { return group_sum_rt(v, P); };
+      auto gsum = [&](float v) { return PT == 16 ? group_sum<16>(v) : group_sum_rt(v, P); };
       const float rel_sum = gsum(gain);
       float mrr = (live && lbr >= 1.f) ? 1.f / (float)(r + 1) : 0.f;
-      mrr = group_max_rt(mrr, P);
+      mrr = gmax(mrr);
       float e_term = 0.f;
       if (metric_mask & ULTR_METRIC_ERR) {
         const float rel = gain / powf(2.f, max_label);  // metrics.py:312-313
@@ -217,9 +242,21 @@ __device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bi
 #pragma unroll
       for (int j = 0; j < kAccSlots; ++j)
         if (j == slot) val = vacc[j];
-      for (int off = P; off < 64; off <<= 1) val += __shfl_xor(val, off, 64);  // the other lists of this wave
+      if (PT == 16) {  // the other lists of this wave
+        float o1, o2;
+        val = xor16_partner(val, &o1);
+        val += o1;
+        val = xor32_partner(val, &o2) + o2;
+      } else {
+        for (int off = P; off < 64; off <<= 1) val += __shfl_xor(val, off, 64);
+      }
       if ((tid & 63) < P) s_w[(tid >> 6) * nout + o] = val;
     }
+}
+
+__device__ __forceinline__ void metrics_short_lists(const MetricsArgs& a, int bid, int nb, float* s_vals) {
+  if (a.P == 16) metrics_short_lists_t<16>(a, bid, nb, s_vals);  // uniform over the launch
+  else metrics_short_lists_t<0>(a, bid, nb, s_vals);
 }
 
 // Block partial sums in fixed order; the last workgroup to arrive adds the rows and divides by B (reduce_mean over lists).
