@@ -1422,7 +1422,9 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
     ultr::ProfScope prof_("finalize_fused_kernel", st);
     hipLaunchKernelGGL(finalize_fused_kernel, dim3(fblocks + (unsigned)(fr.m_pad + fr.l_pad)), dim3(kThreads), 0, st, fr);
   }
-  return check_launch("finalize_fused_kernel");
+  rc = check_launch("finalize_fused_kernel");
+  if (rc) g_pending_mtail.on = false;  // no rows were written: nothing for the update launch to add
+  return rc;
 }
 
 extern "C" int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, void* workspace, float* theta, float* acc,
