@@ -103,10 +103,10 @@ def test_bf16_weight_copies_follow_the_parameters():
 
 
 def test_bf16_step_stays_fused_beyond_the_fp32_row_limit():
-    """The fp32 fused step hands over to the per-launch plan above 8192 rows; the bf16 step does not (it is faster at
-    every size).  1024 lists of 10: still the fused path, still inside the stated bound."""
+    """The fp32 fused step hands over to the per-launch plan above 12288 rows; the bf16 step does not (it is faster at
+    every size).  1536 lists of 10: still the fused path, still inside the stated bound."""
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
-    B, L, F = 1024, 10, 136
+    B, L, F = 1536, 10, 136
     data = SyntheticData(2000, L, F, seed=9, pad_frac=0.1)
     out = {}
     for dt in ('f32', 'bf16'):

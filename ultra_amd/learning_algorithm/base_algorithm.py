@@ -389,10 +389,10 @@ class BaseAlgorithm(ABC):
     fused_step = os.environ.get('ULTR_FUSED_STEP', '1') != '0'
 
     # The fused step's workgroups own whole lists and each streams every weight: it wins while the batch fits the chip
-    # about three times over (measured crossover against the per-launch plan near 7.5 k rows: 97 against 131 us at
-    # 2560 rows, 1094 against 900 us at 40960); beyond that the per-layer kernels, which share weight tiles between
-    # workgroups, are the better plan.  ULTR_FUSED_MAX_ROWS overrides the threshold.
-    fused_max_rows = int(os.environ.get('ULTR_FUSED_MAX_ROWS', '8192'))
+    # a few times over (measured against the per-launch plan: 90 against 131 us at 2560 rows, 279 against 297 at 10240,
+    # 414 against 405 at 15360, 1094 against 808 at 40960); beyond that the per-layer kernels, which share weight
+    # tiles between workgroups, are the better plan.  ULTR_FUSED_MAX_ROWS overrides the threshold.
+    fused_max_rows = int(os.environ.get('ULTR_FUSED_MAX_ROWS', '12288'))
 
     def _fused_ok(self, batch):
         """Short lists run forward + loss gradient + backward as ONE call (ultr_dnn_train_fused)."""
