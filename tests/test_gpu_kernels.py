@@ -1015,12 +1015,12 @@ def test_online_kernels_short_and_long_list_layouts_agree(L, model_file, stochas
 
 @pytest.mark.parametrize('model_file,stochastic,Lmax', [('pbm_0.1_1.0_4_1.0.json', False, 10), ('ubm_0.1_1_4_1.0.json', False, 16),
                                                         ('cascade_0.1_1.0_4_1.0.json', True, 10),
-                                                        ('cascade_0.1_1.0_4_1.0.json', False, 13)])
+                                                        ('cascade_0.1_1.0_4_1.0.json', False, 13), ('oracle', False, 10)])
 def test_online_kernel_many_lists_layout_agrees(L, model_file, stochastic, Lmax):
     """From 131072 lists of at most 16 candidates on a lane owns a whole list.  The same lists padded to 17 columns go
     through the workgroup-per-list kernel and must come out identical: ranking, Plackett-Luce noise, every re-sampling
     round of the clicks."""
-    model = load_json(model_file)
+    model = {'model_name': 'oracle'} if model_file == 'oracle' else load_json(model_file)
     rng = np.random.RandomState(Lmax)
     B, wide, Ls, n_rows = 140001, 17, 10, 4000
     lens = rng.randint(0, Lmax + 1, size=B)
