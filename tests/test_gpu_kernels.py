@@ -341,8 +341,10 @@ def test_dla_loss_kernel(L, B, Ls, loss_func, prob, maxw):
     assert relerr(lw.cpu().numpy(), want_lw) < RTOL
 
 
+# L <= 16: lane per (list, rank); beyond: thread per list; from 32768 lists of at most 16 on (softmax loss): lane per list
 @pytest.mark.parametrize('B,Ls,loss_func', [(256, 10, 0), (777, 7, 0), (256, 10, 1), (20000, 10, 0), (130, 16, 1),
-                                            (128, 24, 0), (96, 24, 1)])  # L <= 16: lane per (list, rank); beyond: thread per list
+                                            (128, 24, 0), (96, 24, 1), (40000, 10, 0), (33001, 16, 0), (32768, 3, 0),
+                                            (40000, 10, 1)])
 def test_ipw_loss_kernel(L, B, Ls, loss_func):
     rng = np.random.RandomState(3)
     scores, clicks = _scores_clicks(rng, B, Ls)

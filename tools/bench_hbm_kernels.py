@@ -5,7 +5,7 @@ kernels"; SURVEY.md 8d: K1, K4-K12 are HBM-bound and at B <= 4096 launch-latency
 reported from a large-batch run).  Algorithmic bytes per unit are SURVEY 8d's:
 
   click        8 L B per candidate list (read labels fp32, write clicks)
-  DLA loss     12 L B per list (read scores and clicks, write d_scores)
+  DLA loss     12 L B per list (read scores and clicks, write d_scores); IPW loss 16 L B (the weights as well)
   metrics      8 L B per list (read scores and labels) + 4 B per metric
   online feed  20 Lmax B per list (doc ids, labels, scores in; doc ids, clicks out)
   optimiser    20 B per parameter (read g, acc, theta; write acc, theta) + 8 B for the norm pass
@@ -73,6 +73,10 @@ def main():
         report('dla_loss fwd+bwd', B, 'lists', 12 * Ls * B, timed(lambda: L.check(lib.ultr_loss_dla_fwdbwd(
             L.ptr(scores), L.ptr(c_lb), B, Ls, L.ptr(pp), 0, 0, -1.0, L.ptr(d), L.ptr(pg), L.ptr(lw), L.ptr(stats), L.ptr(ws),
             st), 'dla')))
+        pw = torch.rand((Ls, B), device=dev) + 0.5
+        istats = torch.zeros(2 + Ls, device=dev)
+        report('ipw_loss fwd+bwd', B, 'lists', 16 * Ls * B, timed(lambda: L.check(lib.ultr_loss_ipw_fwdbwd(
+            L.ptr(scores), L.ptr(c_lb), L.ptr(pw), B, Ls, 0, L.ptr(d), L.ptr(istats), L.ptr(lw), L.ptr(ws), st), 'ipw')))
         plan = M.MetricPlan(['mrr', 'ndcg'], [3, 5, 10])
         out = torch.zeros(plan.n_out, device=dev)
         mws = M.metrics_workspace(B, plan, dev)

@@ -76,6 +76,21 @@ __global__ void __launch_bounds__(kLossThreads) ipw_loss_small_kernel(IpwArgs a)
   ipw_loss_small_body(a, blockIdx.x, gridDim.x, s_acc, s_part);
 }
 
+constexpr int kDlaListsMinB = 32768;
+constexpr int kDlaListsMaxBlocks = 512;  // one partial row per workgroup for the last one to add
+// Many short lists (B >= kDlaListsMinB, L <= 16, softmax loss): one lane per list, body in loss_body.hpp.
+template <int LT>
+__global__ void __launch_bounds__(kLossThreads) ipw_loss_lists_kernel(IpwArgs a) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  ipw_loss_lists_body<LT>(a, blockIdx.x, gridDim.x, s_acc, s_part);
+}
+template <int LT>
+static void launch_ipw_lists(const IpwArgs& a, unsigned nb, hipStream_t st) {
+  if (a.L == LT) hipLaunchKernelGGL(ipw_loss_lists_kernel<LT>, dim3(nb), dim3(kLossThreads), 0, st, a);
+  else if constexpr (LT > 1) launch_ipw_lists<LT - 1>(a, nb, st);
+}
+
 __global__ void ipw_weights_kernel(const float* __restrict__ clicks, int B, int L, const float* __restrict__ ipw,
                                    int n_ipw, float* __restrict__ pw) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,8 +252,6 @@ __global__ void __launch_bounds__(kLossThreads) dla_loss_small_kernel(DlaArgs a)
 }
 
 // Many short lists (B >= kDlaListsMinB, L <= 16): one lane per list, body in loss_body.hpp.
-constexpr int kDlaListsMinB = 32768;
-constexpr int kDlaListsMaxBlocks = 512;  // one partial row per workgroup for the last one to add
 template <int LT>
 __global__ void __launch_bounds__(kLossThreads) dla_loss_lists_kernel(DlaArgs a) {
   __shared__ float s_acc[kMaxStat];
@@ -535,6 +548,14 @@ extern "C" int ultr_loss_ipw_fwdbwd(const float* scores, const float* clicks, co
   if (rc) return rc;
   rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
   if (rc) return rc;
+  if (L <= 16 && B >= kDlaListsMinB && B <= (1 << 30) && loss_func == ULTR_LOSS_SOFTMAX) {  // one lane per list
+    const unsigned nb = (unsigned)(cdiv(B, kLossThreads) < kDlaListsMaxBlocks ? cdiv(B, kLossThreads) : kDlaListsMaxBlocks);
+    {
+      ultr::ProfScope prof_("ipw_loss_lists_kernel", as_stream(stream));
+      launch_ipw_lists<16>(a, nb, as_stream(stream));
+    }
+    return check_launch("ipw_loss_lists_kernel");
+  }
   if (L <= 16) {
     PendingLoss p{};
     p.kind = ULTR_RIDE_IPW; p.ipw = a; p.nblocks = small_blocks(B);
@@ -643,14 +664,10 @@ extern "C" int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, in
   const unsigned dla_blocks = (unsigned)(cdiv(B, kLossThreads) < 1024 ? cdiv(B, kLossThreads) : 1024);
   {
     ultr::ProfScope prof_("dla_loss_kernel", as_stream(stream));
-    if (L <= 16)
-      hipLaunchKernelGGL(dla_loss_kernel<16>, dim3(dla_blocks), dim3(kLossThreads), 0,
-                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
-                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
-    else
-      hipLaunchKernelGGL(dla_loss_kernel<64>, dim3(dla_blocks), dim3(kLossThreads), 0,
-                         as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
-                         max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
+    // (lists of at most 16 have returned above: only the long-list build of the list-per-thread kernel is used)
+    hipLaunchKernelGGL(dla_loss_kernel<64>, dim3(dla_blocks), dim3(kLossThreads), 0,
+                       as_stream(stream), scores, clicks, B, L, prop_params, loss_func, logits_to_prob,
+                       max_propensity_weight, d_scores, prop_grads, list_weights, stats, ws);
   }
   return check_launch("dla_loss_kernel");
 }

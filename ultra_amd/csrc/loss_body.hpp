@@ -413,6 +413,72 @@ __device__ __forceinline__ void ipw_loss_small_body(const IpwArgs& a, unsigned i
   finish_stats(s_acc, 2 + L, 2, a.ws, a.stats, bid, nb);
 }
 
+// IPW / naive softmax loss for MANY short lists (exactly LT <= 16 ranks): one lane per list, as dla_loss_lists_body.
+template <int LT>
+__device__ __forceinline__ void ipw_loss_lists_body(const IpwArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                                    float* s_part) {
+#pragma clang fp contract(off)
+  const int B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float num = 0.f, den = 0.f, wmax[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) wmax[l] = -INFINITY;
+  auto at = [](const float* row, unsigned int off) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + off); };
+  auto at_w = [](float* row, unsigned int off) { return reinterpret_cast<float*>(reinterpret_cast<char*>(row) + off); };
+#pragma unroll 1
+  for (unsigned int b = bid * kLossThreads + tid; b < (unsigned int)B; b += nb * kLossThreads) {
+    const unsigned int off = b * 4u;
+    float o[LT], c[LT], w[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      o[l] = *at(a.scores + (long long)l * B, off);
+      c[l] = *at(a.clicks + (long long)l * B, off);
+      if (!a.ipw_table) w[l] = *at(a.pw + (long long)l * B, off);
+    }
+    if (a.ipw_table) {
+#pragma unroll
+      for (int l = 0; l < LT; ++l) w[l] = c[l] > 0.f ? a.ipw_table[l < a.n_ipw ? l : a.n_ipw - 1] : 0.f;
+    }
+    float m = o[0];
+#pragma unroll
+    for (int l = 1; l < LT; ++l) m = fmaxf(m, o[l]);
+    float ex[LT], se = 0.f, S = 0.f, lw = 0.f;
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      wmax[l] = fmaxf(wmax[l], w[l]);
+      if (a.pw_out) *at_w(a.pw_out + (long long)l * B, off) = w[l];
+      ex[l] = fast_exp(o[l] - m);
+      se += ex[l];
+      S += (c[l] + 0.0000001f) * w[l];
+      lw += w[l] * fminf(fmaxf(c[l], 0.f), 1.f);
+    }
+    const float rse = fast_rcp(se), lse = m + fast_log(se);
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      const float wl = (c[l] + 0.0000001f) * w[l];
+      num -= wl * (o[l] - lse);
+      *at_w(a.d_scores + (long long)l * B, off) = ex[l] * rse * S - wl;
+    }
+    den += S;
+    if (a.list_weights) a.list_weights[b] = lw / (float)LT;
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  float* mine = s_part + wid * kMaxStat;
+  if (lane == 0) {
+    mine[0] = num;
+    mine[1] = den;
+  }
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    const float mx = wave_max(wmax[l]);
+    if (lane == 0) mine[2 + l] = mx;
+  }
+  BlockStats bs{s_part};
+  bs.combine(s_acc, 2 + LT, 2);
+  finish_stats(s_acc, 2 + LT, 2, a.ws, a.stats, bid, nb);
+}
+
 // ------------------------------------------------------------------------------------------
 // Regression-EM for short lists (regression_EM.py:116-176)
 // stats: [0] sum loss_b [1] B [2+l] M-step numerator [2+L+l] sum ranker_label [2+2L+l] sum clicks
