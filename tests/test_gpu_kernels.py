@@ -416,6 +416,46 @@ def test_rem_loss_kernel(L, B, Ls):
     assert not torch.equal(y1, y) and ((y1 == 0) | (y1 == 1)).all() and (y1 >= c).all()
 
 
+@pytest.mark.parametrize('B,Ls', [(40000, 10), (33001, 16), (32768, 3)])
+def test_rem_loss_kernel_many_lists(L, B, Ls):
+    """From 32768 lists on (Philox draws, L <= 16) a lane owns a whole list: labels and gradients bit-identical to the
+    16-lane kernel on a prefix of the lists (same draws, same element arithmetic), batch statistics against float64 sums
+    of the kernel's own elementwise outputs."""
+    rng = np.random.RandomState(B % 1000)
+    scores, clicks = _scores_clicks(rng, B, Ls)
+    p = rng.uniform(0.2, 0.95, size=Ls)
+    bias = 0.25
+    s, c = dev(scores.T, torch.float32), dev(clicks.T, torch.float32)
+    prop, bd = dev(p, torch.float32), dev([bias], torch.float32)
+
+    def run(s_, c_, n):
+        d, y = torch.empty_like(s_), torch.empty_like(s_)
+        lw = torch.empty(n, dtype=torch.float32, device='cuda')
+        stats = torch.zeros(3 + 3 * Ls, dtype=torch.float32, device='cuda')
+        db = torch.zeros(1, dtype=torch.float32, device='cuda')
+        ws = _loss_ws(L, n, Ls)
+        for _ in range(2):  # twice: the arrival counter must be left clean
+            L.check(L.lib().ultr_loss_rem_fwdbwd(L.ptr(s_), L.ptr(c_), n, Ls, L.ptr(prop), L.ptr(bd), None, 0x5EED, 9, None, 0,
+                                                 L.ptr(d), L.ptr(y), L.ptr(lw), L.ptr(stats), L.ptr(db), L.ptr(ws), stream(L)),
+                    'rem')
+        return d, y, lw, stats.cpu().numpy().astype(np.float64), db.item()
+    d, y, lw, st, db = run(s, c, B)
+    n_small = 20000
+    d2, y2, lw2, _, _ = run(s[:, :n_small].contiguous(), c[:, :n_small].contiguous(), n_small)
+    assert torch.equal(d[:, :n_small], d2) and torch.equal(y[:, :n_small], y2)
+    assert relerr(lw[:n_small].cpu().numpy(), lw2.cpu().numpy()) < 1e-6
+    yk, x = y.cpu().numpy().T.astype(np.float64), scores.astype(np.float32).astype(np.float64) + np.float32(bias)
+    g = 1.0 / (1.0 + np.exp(-x))
+    ck = clicks.astype(np.float64)
+    assert st[1] == B
+    assert abs(st[0] - (np.maximum(x, 0) - x * yk + np.log1p(np.exp(-np.abs(x)))).sum()) < RTOL * st[0]
+    assert relerr(st[2:2 + Ls], (ck + (1 - ck) * p * (1 - g) / (1 - p * g)).sum(0)) < RTOL
+    assert np.array_equal(st[2 + Ls:2 + 2 * Ls], yk.sum(0)) and np.array_equal(st[2 + 2 * Ls:2 + 3 * Ls], ck.sum(0))
+    assert abs(st[2 + 3 * Ls] - d.double().sum().item()) < 1e-3 * B and abs(db - st[2 + 3 * Ls]) < 1e-3
+    assert relerr(lw.cpu().numpy(), (np.clip(ck, 0, 1) / p).mean(1)) < RTOL
+    assert ((yk == 0) | (yk == 1)).all() and (yk >= ck).all()
+
+
 @pytest.mark.parametrize('B,Ls', [(256, 10), (900, 5), (64, 32), (20000, 10), (333, 16)])  # short-list kernel: L <= 16
 def test_pd_loss_kernel(L, B, Ls):
     rng = np.random.RandomState(13)

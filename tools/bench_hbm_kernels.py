@@ -77,6 +77,11 @@ def main():
         istats = torch.zeros(2 + Ls, device=dev)
         report('ipw_loss fwd+bwd', B, 'lists', 16 * Ls * B, timed(lambda: L.check(lib.ultr_loss_ipw_fwdbwd(
             L.ptr(scores), L.ptr(c_lb), L.ptr(pw), B, Ls, 0, L.ptr(d), L.ptr(istats), L.ptr(lw), L.ptr(ws), st), 'ipw')))
+        prop = torch.full((Ls,), 0.6, device=dev)
+        rstats = torch.zeros(3 + 3 * Ls, device=dev)
+        report('rem_loss fwd+bwd', B, 'lists', 12 * Ls * B, timed(lambda: L.check(lib.ultr_loss_rem_fwdbwd(
+            L.ptr(scores), L.ptr(c_lb), B, Ls, L.ptr(prop), None, None, 2024, 1, None, 0, L.ptr(d), None, L.ptr(lw),
+            L.ptr(rstats), None, L.ptr(ws), st), 'rem')))
         plan = M.MetricPlan(['mrr', 'ndcg'], [3, 5, 10])
         out = torch.zeros(plan.n_out, device=dev)
         mws = M.metrics_workspace(B, plan, dev)

@@ -91,6 +91,18 @@ static void launch_ipw_lists(const IpwArgs& a, unsigned nb, hipStream_t st) {
   else if constexpr (LT > 1) launch_ipw_lists<LT - 1>(a, nb, st);
 }
 
+template <int LT>
+__global__ void __launch_bounds__(kLossThreads) rem_loss_lists_kernel(RemArgs a) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  rem_loss_lists_body<LT>(a, blockIdx.x, gridDim.x, s_acc, s_part);
+}
+template <int LT>
+static void launch_rem_lists(const RemArgs& a, unsigned nb, hipStream_t st) {
+  if (a.L == LT) hipLaunchKernelGGL(rem_loss_lists_kernel<LT>, dim3(nb), dim3(kLossThreads), 0, st, a);
+  else if constexpr (LT > 1) launch_rem_lists<LT - 1>(a, nb, st);
+}
+
 __global__ void ipw_weights_kernel(const float* __restrict__ clicks, int B, int L, const float* __restrict__ ipw,
                                    int n_ipw, float* __restrict__ pw) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -700,6 +712,16 @@ extern "C" int ultr_loss_rem_fwdbwd(const float* scores, const float* clicks, in
   ULTR_REQUIRE(propensity && d_scores && stats, ULTR_EINVAL, "ultr_loss_rem_fwdbwd: null pointer");
   rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
   if (rc) return rc;
+  if (L <= 16 && B >= kDlaListsMinB && B <= (1 << 30) && !uniforms) {  // very many short lists: one lane per list
+    const RemArgs a{scores, clicks, B, L, propensity, sigmoid_prob_b, uniforms, seed, step, step_ctr, slot_base, d_scores,
+                    ranker_labels, list_weights, stats, d_bias, ws};
+    const unsigned nb = (unsigned)(cdiv(B, kLossThreads) < kDlaListsMaxBlocks ? cdiv(B, kLossThreads) : kDlaListsMaxBlocks);
+    {
+      ultr::ProfScope prof_("rem_loss_lists_kernel", as_stream(stream));
+      launch_rem_lists<16>(a, nb, as_stream(stream));
+    }
+    return check_launch("rem_loss_lists_kernel");
+  }
   if (L <= 16) {
     PendingLoss p{};
     p.kind = ULTR_RIDE_REM; p.nblocks = small_blocks(B);

@@ -494,9 +494,8 @@ struct RemArgs {
 // One (list b, rank r) element: E-step posteriors, the Bernoulli ranker label and d loss / d score = sigmoid - label.
 // Elementwise, so the backward pass's first launch can evaluate it for its own rows (ultr_loss_rem_deferred).
 struct RemElem { float x, g, y, d, p_e1_r0_c0; };
-// rem_elem_v takes the element's score and click by value (the fused training step has them on chip).
-__device__ __forceinline__ RemElem rem_elem_v(const RemArgs& a, float bias, float p, unsigned int step, long long b, int r,
-                                              long long e, float score, float c) {
+// rem_elem_u: the arithmetic, given the element's uniform draw.
+__device__ __forceinline__ RemElem rem_elem_u(float bias, float p, float score, float c, float u) {
 #pragma clang fp contract(off)
   RemElem v;
   v.x = score + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
@@ -505,6 +504,14 @@ __device__ __forceinline__ RemElem rem_elem_v(const RemArgs& a, float bias, floa
   v.p_e1_r0_c0 = p * (1.f - v.g) / den;              // :140-141
   const float p_e0_r1_c0 = (1.f - p) * v.g / den;    // :142-143
   const float p_r1 = c + (1.f - c) * p_e0_r1_c0;     // :147-148
+  v.y = ceilf(p_r1 - u);      // get_bernoulli_sample (:39)
+  v.y = v.y > 0.f ? v.y : 0.f;  // ceil(-0.x) = -0 -> 0
+  v.d = v.g - v.y;
+  return v;
+}
+// rem_elem_v takes the element's score and click by value (the fused training step has them on chip) and finds its draw.
+__device__ __forceinline__ RemElem rem_elem_v(const RemArgs& a, float bias, float p, unsigned int step, long long b, int r,
+                                              long long e, float score, float c) {
   float u;
   if (a.uniforms) {
     u = a.uniforms[e];
@@ -513,10 +520,7 @@ __device__ __forceinline__ RemElem rem_elem_v(const RemArgs& a, float bias, floa
                                       (uint32_t)(a.seed >> 32));
     u = u24(philox_word(rnd, r));
   }
-  v.y = ceilf(p_r1 - u);      // get_bernoulli_sample (:39)
-  v.y = v.y > 0.f ? v.y : 0.f;  // ceil(-0.x) = -0 -> 0
-  v.d = v.g - v.y;
-  return v;
+  return rem_elem_u(bias, p, score, c, u);
 }
 __device__ __forceinline__ RemElem rem_elem(const RemArgs& a, float bias, float p, unsigned int step, long long b, int r,
                                             long long e) {
@@ -576,6 +580,78 @@ __device__ __forceinline__ void rem_loss_small_body(const RemArgs& a, unsigned i
   bs.combine(s_acc, 3 + 3 * L, 1 << 30);
   if (finish_stats(s_acc, 3 + 3 * L, 1 << 30, a.ws, a.stats, bid, nb)) {
     if (threadIdx.x == 0 && a.d_bias) a.d_bias[0] = s_acc[2 + 3 * L];  // un-normalised d loss / d sigmoid_prob_b
+  }
+}
+
+// Regression-EM for MANY short lists (exactly LT <= 16 ranks, Philox draws): one lane per list, as dla_loss_lists_body;
+// one Philox block serves four ranks.  Same draws and element arithmetic as rem_loss_small_body.
+template <int LT>
+__device__ __forceinline__ void rem_loss_lists_body(const RemArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                                    float* s_part) {
+  const int B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float bias = a.bias_ptr ? a.bias_ptr[0] : 0.f;
+  const unsigned int step = a.step + (a.step_ctr ? a.step_ctr[0] : 0u);
+  float p[LT], ms[LT], ys[LT], cs[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    p[l] = a.propensity[l];
+    ms[l] = ys[l] = cs[l] = 0.f;
+  }
+  float loss = 0.f, cnt = 0.f, dsum = 0.f;
+  auto at = [](const float* row, unsigned int off) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + off); };
+  auto at_w = [](float* row, unsigned int off) { return reinterpret_cast<float*>(reinterpret_cast<char*>(row) + off); };
+#pragma unroll 1
+  for (unsigned int b = bid * kLossThreads + tid; b < (unsigned int)B; b += nb * kLossThreads) {
+    const unsigned int off = b * 4u;
+    float o[LT], c[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      o[l] = *at(a.scores + (long long)l * B, off);
+      c[l] = *at(a.clicks + (long long)l * B, off);
+    }
+    float lwt = 0.f;
+    Philox4 rnd{};
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      if ((l & 3) == 0)
+        rnd = philox4x32_10(a.slot_base + b, 0x52454Du, (uint32_t)(l >> 2), step, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+      const uint32_t word = (l & 3) == 0 ? rnd.w0 : (l & 3) == 1 ? rnd.w1 : (l & 3) == 2 ? rnd.w2 : rnd.w3;
+      const RemElem v = rem_elem_u(bias, p[l], o[l], c[l], u24(word));
+      loss += sig_ce(v.y, v.x);       // :159-165
+      *at_w(a.d_scores + (long long)l * B, off) = v.d;
+      dsum += v.d;
+      if (a.ranker_labels) *at_w(a.ranker_labels + (long long)l * B, off) = v.y;
+      ms[l] += c[l] + (1.f - c[l]) * v.p_e1_r0_c0;  // :153
+      ys[l] += v.y;
+      cs[l] += c[l];
+      lwt += fminf(fmaxf(c[l], 0.f), 1.f) / p[l];  // propensity_weights = 1/propensity (:176)
+    }
+    cnt += 1.f;
+    if (a.list_weights) a.list_weights[b] = lwt / (float)LT;
+  }
+  loss = wave_sum(loss);
+  cnt = wave_sum(cnt);
+  dsum = wave_sum(dsum);
+  float* mine = s_part + wid * kMaxStat;
+  if (lane == 0) {
+    mine[0] = loss;
+    mine[1] = cnt;
+    mine[2 + 3 * LT] = dsum;
+  }
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    const float m1 = wave_sum(ms[l]), y1 = wave_sum(ys[l]), c1 = wave_sum(cs[l]);
+    if (lane == 0) {
+      mine[2 + l] = m1;
+      mine[2 + LT + l] = y1;
+      mine[2 + 2 * LT + l] = c1;
+    }
+  }
+  BlockStats bs{s_part};
+  bs.combine(s_acc, 3 + 3 * LT, 1 << 30);
+  if (finish_stats(s_acc, 3 + 3 * LT, 1 << 30, a.ws, a.stats, bid, nb)) {
+    if (threadIdx.x == 0 && a.d_bias) a.d_bias[0] = s_acc[2 + 3 * LT];  // un-normalised d loss / d sigmoid_prob_b
   }
 }
 
