@@ -214,7 +214,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& p, const int b
   float* dW = p.grads + p.off_W[j] + (long long)k * ldn;
   const float gam = p.has_ln ? p.params[p.off_gamma[j] + k] : 1.f;
   const float bet = p.has_ln ? p.params[p.off_beta[j] + k] : 0.f;
-  // Slab sums in a fixed order with every load of a round in flight at once (up to 16 slabs x 2 streams): a thread
+  // Slab sums in a fixed order with every load of a round in flight at once (up to 8 slabs x 2 streams): a thread
   // that walks its slabs four at a time pays one L2 round trip per four slabs, and this launch sits at the end of the
   // backward pass with nothing to hide behind.  Narrow layers (N <= 128, a power of two) put the idle threads to work:
   // the block's 256 / N thread groups take alternate slabs and meet in LDS, again in fixed order.
@@ -225,16 +225,16 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& p, const int b
   const int groups = (N <= 128 && (N & (N - 1)) == 0) ? (int)blockDim.x / N : 1;
   auto slab_sums = [&](int n, int s0, int sstep, float* Gout, float* Sout) {
     float G4[4] = {0.f, 0.f, 0.f, 0.f}, S4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int base = s0; base < ns; base += 16 * sstep) {
-      float g[16], sv[16];
+    for (int base = s0; base < ns; base += 8 * sstep) {  // eight slabs a round: every plan in use has at most eight
+      float g[8], sv[8];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int sl = min(base + u * sstep, ns - 1);
         g[u] = gsl[(long long)sl * gstride + n];
         sv[u] = ssl[(long long)sl * ldn + n];
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
+      for (int u = 0; u < 8; ++u)
         if (base + u * sstep < ns) {
           G4[u & 3] += g[u];
           S4[u & 3] += sv[u];

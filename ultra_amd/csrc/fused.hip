@@ -1050,12 +1050,13 @@ struct FinalizeFusedArgs {
   MetricsArgs m; int m_blocks, m_pad;
   int ride; DlaArgs dla; IpwArgs ipw; RemArgs rem; PdArgs pd; int l_blocks, l_pad;
 };
+template <int RIDE>  // the loss rider compiled in (the kernel's register count is the maximum over its bodies)
 __global__ void __launch_bounds__(kThreads) finalize_fused_kernel(FinalizeFusedArgs p) {
   int id = blockIdx.x;
   if (id < p.m_pad) {
     if (id >= p.m_blocks) return;
     __shared__ float s_vals[4 * kMaxOut];
-    metrics_short_lists(p.m, id, p.m_blocks, s_vals);
+    metrics_short_lists_t<16>(p.m, id, p.m_blocks, s_vals);  // (other group widths get a launch of their own)
     __syncthreads();
     metrics_finish(p.m, id, p.m_blocks, s_vals, kMetThreads / 64);
     return;
@@ -1066,10 +1067,10 @@ __global__ void __launch_bounds__(kThreads) finalize_fused_kernel(FinalizeFusedA
     __shared__ float s_acc[kMaxStat];
     __shared__ float s_part[4 * kMaxStat];
     __shared__ float s_tower[4 * 16];
-    if (p.ride == ULTR_RIDE_DLA) dla_loss_small_body(p.dla, id, p.l_blocks, s_acc, s_part, s_tower);
-    if (p.ride == ULTR_RIDE_IPW) ipw_loss_small_body(p.ipw, id, p.l_blocks, s_acc, s_part);
-    if (p.ride == ULTR_RIDE_REM) rem_loss_small_body(p.rem, id, p.l_blocks, s_acc, s_part);
-    if (p.ride == ULTR_RIDE_PD) pd_loss_small_body(p.pd, id, p.l_blocks, s_acc, s_part, s_tower);
+    if (RIDE == ULTR_RIDE_DLA) dla_loss_small_body(p.dla, id, p.l_blocks, s_acc, s_part, s_tower);
+    if (RIDE == ULTR_RIDE_IPW) ipw_loss_small_body(p.ipw, id, p.l_blocks, s_acc, s_part);
+    if (RIDE == ULTR_RIDE_REM) rem_loss_small_body(p.rem, id, p.l_blocks, s_acc, s_part);
+    if (RIDE == ULTR_RIDE_PD) pd_loss_small_body(p.pd, id, p.l_blocks, s_acc, s_part, s_tower);
     return;
   }
   finalize_body(p.f, id - p.l_pad);
@@ -1393,7 +1394,8 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   f.outpart = ws + P.outpart; f.out_blocks = P.nwg; f.Kout = P.K[H];
   f.sumsq = sumsq;
   const unsigned fblocks = (unsigned)(start + (3 * P.K[H] + 1 + 63) / 64);
-  if (g_pending_metrics.on && g_pending_metrics.nblocks > 64) {  // too big to ride along: a launch of its own
+  // too big to ride along, or lists of at most 8 (the rider is compiled for 16-lane groups): a launch of its own
+  if (g_pending_metrics.on && (g_pending_metrics.nblocks > 64 || g_pending_metrics.a.P != 16)) {
     g_pending_metrics.on = false;
     rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, st);
     if (rc) return rc;
@@ -1420,7 +1422,11 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   // riders still read the current batch, which the assembly overwrites)
   {
     ultr::ProfScope prof_("finalize_fused_kernel", st);
-    hipLaunchKernelGGL(finalize_fused_kernel, dim3(fblocks + (unsigned)(fr.m_pad + fr.l_pad)), dim3(kThreads), 0, st, fr);
+    const dim3 grid(fblocks + (unsigned)(fr.m_pad + fr.l_pad));
+    if (fr.ride == ULTR_RIDE_DLA) hipLaunchKernelGGL(finalize_fused_kernel<ULTR_RIDE_DLA>, grid, dim3(kThreads), 0, st, fr);
+    else if (fr.ride == ULTR_RIDE_IPW) hipLaunchKernelGGL(finalize_fused_kernel<ULTR_RIDE_IPW>, grid, dim3(kThreads), 0, st, fr);
+    else if (fr.ride == ULTR_RIDE_REM) hipLaunchKernelGGL(finalize_fused_kernel<ULTR_RIDE_REM>, grid, dim3(kThreads), 0, st, fr);
+    else hipLaunchKernelGGL(finalize_fused_kernel<ULTR_RIDE_PD>, grid, dim3(kThreads), 0, st, fr);
   }
   rc = check_launch("finalize_fused_kernel");
   if (rc) g_pending_mtail.on = false;  // no rows were written: nothing for the update launch to add

@@ -680,12 +680,15 @@ __device__ __forceinline__ float pd_lane(float o, float c, float tp_k, float tm_
       const float m1 = fminf(1.f, fmaxf(c - cj, 0.f));  // min(1, relu(c_k - c_j))  (:147-150)
       const float m2 = fminf(1.f, fmaxf(cj - c, 0.f));
       if (live && j != r && (m1 > 0.f || m2 > 0.f)) {
-        // one exponential serves both: softplus(d) = max(d, 0) + log1p(e), sigmoid(d) = (d >= 0 ? 1 : e) / (1 + e)
+        // one exponential serves both: softplus(d) = max(d, 0) + log1p(e), sigmoid(d) = (d >= 0 ? 1 : e) / (1 + e).
+        // Hardware exp / rcp / log as in dla_lane (1 ulp each on e in (0, 1] and 1 + e in (1, 2]: an absolute error of
+        // 1e-7 on a pair's loss and sigmoid, far inside the 1e-5 parity bound; the lanes run ~16 of these in a row on one
+        // wave per SIMD, where libm's expf / log1pf / divide cost 2 us of a 10 us rider)
         const float diff = oj - o;
-        const float ex = expf(-fabsf(diff));
-        const float inv = 1.f / (1.f + ex);
+        const float ex = fast_exp(-fabsf(diff));
+        const float inv = fast_rcp(1.f + ex);
         const float sg = diff >= 0.f ? inv : ex * inv;   // d softplus(o_j - o_k) / d o_j
-        if (WITH_PL) pl[j] += m1 * (fmaxf(diff, 0.f) + log1pf(ex));   // softplus(o_j - o_k)  (:151-155)
+        if (WITH_PL) pl[j] += m1 * (fmaxf(diff, 0.f) + fast_log(1.f + ex));   // softplus(o_j - o_k)  (:151-155)
         acc += m2 / (tpj * tm_k) * (1.f - sg) - m1 / (tp_k * tmj) * sg;  // pair (j, k): sig(o_k - o_j) ; pair (k, j)
       }
     }
