@@ -209,7 +209,7 @@ def main():
                          'one GPU, 2 on several')
     ap.add_argument('--graph_steps', type=int, default=0,
                     help='--graph 1 only: consecutive steps captured into one hipGraph (--steps must be a multiple); '
-                         '0 = 4, or the largest of 4 / 2 / 1 that divides --steps')
+                         '0 = the largest of 8 .. 1 that divides --steps')
     ap.add_argument('--force_collective', action='store_true',
                     help='single-GPU rehearsal of the multi-GPU launch path: a 1-rank RCCL group, all-reduce issued anyway')
     ap.add_argument('--algo_hparams', default='')
@@ -252,7 +252,7 @@ def main():
         data, exp, model, feed = build_world(cfg, args, device)
     use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 2)
     if args.graph_steps <= 0:
-        args.graph_steps = next(k for k in (4, 2, 1) if args.steps % k == 0)
+        args.graph_steps = next(k for k in range(8, 0, -1) if args.steps % k == 0)
     if use_graph == 1 and (world > 1 or args.force_collective):
         use_graph = 2  # the collective is never captured
 
