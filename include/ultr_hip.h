@@ -443,8 +443,16 @@ int ultr_metrics_cancel(void);
  * ends); its address is looked up once per device.  The call makes no hipMalloc / hipFree and no allocating library
  * call.  ULTR_ELIMIT when ultr_metrics_workspace_floats(B, n_topn) exceeds the array.  Every call on a GPU shares
  * that GPU's array: two calls that overlap on one GPU (different streams, different threads) race -- serialise them
- * or use ultr_metrics with workspaces of your own. */
+ * or use ultr_metrics with workspaces of your own.  The same holds for captured graphs: two graphs that each contain
+ * the call must not be replayed concurrently on one GPU.
+ * Graph capture: the FIRST call on a device resolves the array's address (hipGetSymbolAddress), which must happen
+ * outside a capture -- call ultr_metrics_static_prepare() once per device (with that device current) at set-up, or
+ * make one eager call first; a first call on a capturing stream returns ULTR_EINVAL and launches nothing.  After
+ * that the call takes no lock and makes no runtime call besides hipMemsetAsync (32 bytes, captured as a memset node)
+ * and the kernel launch. */
 long long ultr_metrics_static_max_floats(void);
+/* Set-up for ultr_metrics_static on the current device (idempotent, thread-safe); launches nothing. */
+int ultr_metrics_static_prepare(void);
 int ultr_metrics_static(const float* scores, const float* labels, const int* docids, int n_rows,
                         const float* list_weights, const float* u_pred, int B, int Lx, const int* topn_h,
                         int n_topn, int metric_mask, float max_label, float* out, void* stream);

@@ -158,3 +158,24 @@ def test_transposed_weights_follow_external_parameter_writes():
         m1.step(None, feed_dict, False)
         m2.step(None, feed_dict, False)
         assert relerr_floor(m1.model.params.cpu().numpy(), m2.model.params.cpu().numpy(), 1e-4) < 2e-5, step
+
+
+def test_transposed_weights_follow_a_non_fused_update_between_fused_steps():
+    """The C update calls write the parameters in place without touching torch's version counter: a step whose update
+    went through ultr_clip_adagrad / 2 / 3 (here: fused_step switched off for one step) must leave the fused step's
+    streamed weight copies marked stale, so that the next fused step of the same (B, L) rebuilds them."""
+    data = SyntheticData(200, 10, 24, seed=6, pad_frac=0.1)
+    exp = settings('DLA', '', 'hidden_layer_sizes=[64, 48, 32]')
+    m1, feed = make('DLA', data, exp, 64)
+    m2, _ = make('DLA', data, exp, 64)
+    m2.fused_step = False
+    rng = np.random.RandomState(5)
+    for step in range(5):
+        feed_dict, _ = feed.get_batch(data, check_validation=True)
+        u = torch.tensor(rng.uniform(size=(64, 10)).astype(np.float32)).cuda()
+        m1.metric_uniforms = m2.metric_uniforms = u
+        m1.fused_step = step not in (1, 3)   # fused, per-launch, fused, per-launch, fused on the same workspace
+        m1.step(None, feed_dict, False)
+        assert m1._train_bufs['fused'] == m1.fused_step
+        m2.step(None, feed_dict, False)
+        assert relerr_floor(m1.model.params.cpu().numpy(), m2.model.params.cpu().numpy(), 1e-4) < 2e-5, step

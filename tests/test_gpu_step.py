@@ -69,13 +69,16 @@ def compare_params(model, ref, tol):
             assert relerr_floor(got[j][k].reshape(p[k].shape), p[k].detach().numpy(), 1e-3) < tol, (j, k)
 
 
-@pytest.mark.parametrize('hp,B', [('', 256), ('loss_func=sigmoid_loss,l2_loss=0.001', 96),
-                                  ('logits_to_prob=sigmoid,max_propensity_weight=4,ranker_loss_weight=2.0', 96),
-                                  ('grad_strategy=sgd,learning_rate=0.01,max_gradient_norm=0.0', 64)])
-def test_dla_steps_match_reference_graph(hp, B):
+# the last case is BASELINE.json's headline shape (MSLR-10K: 136 features, DNN[512, 256, 128], 256 lists of 10): the
+# compile-time specialised (FAST) instantiation of the fused step against the float64 graph directly
+@pytest.mark.parametrize('hp,B,F,mhp', [('', 256, 24, None), ('loss_func=sigmoid_loss,l2_loss=0.001', 96, 24, None),
+                                        ('logits_to_prob=sigmoid,max_propensity_weight=4,ranker_loss_weight=2.0', 96, 24, None),
+                                        ('grad_strategy=sgd,learning_rate=0.01,max_gradient_norm=0.0', 64, 24, None),
+                                        ('', 256, 136, 'hidden_layer_sizes=[512, 256, 128]')])
+def test_dla_steps_match_reference_graph(hp, B, F, mhp):
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
-    data = SyntheticData(400, 10, 24, seed=3, pad_frac=0.2)
-    exp = settings('DLA', hp)
+    data = SyntheticData(400, 10, F, seed=3, pad_frac=0.2)
+    exp = settings('DLA', hp) if mhp is None else settings('DLA', hp, mhp)
     model, feed = make('DLA', data, exp, B)
     hpd = {k: getattr(model.hparams, k) for k in ('learning_rate', 'max_gradient_norm', 'loss_func', 'logits_to_prob',
                                                    'propensity_learning_rate', 'ranker_loss_weight', 'l2_loss',
@@ -90,6 +93,7 @@ def test_dla_steps_match_reference_graph(hp, B):
         t_in = torch_feed(data, batch)
         u = tie_uniforms(model, rng, B)
         loss, _, summary = model.step(None, feed_dict, False)
+        assert model._train_bufs['fused']  # lists of 10: the fused step is what is being compared
         ref_loss, ref_sum = ref.step(*t_in, u_pred=u)
         assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss), step
         got = summary.as_dict()

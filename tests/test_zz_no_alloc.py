@@ -61,3 +61,31 @@ def test_static_workspace_refuses_what_does_not_fit():
         B *= 2
     with pytest.raises(_lib.UltrError, match='static array holds'):
         _call(True, B, 4, 3)
+
+
+def test_static_workspace_metrics_inside_a_captured_graph():
+    """After the per-device set-up call the entry point can be captured into a hipGraph (it allocates nothing and looks
+    nothing up); two replays on new inputs in the same buffers give what ultr_metrics gives."""
+    lib = _lib.lib()
+    B, L = 300, 10
+    _lib.check(lib.ultr_metrics_static_prepare(), 'ultr_metrics_static_prepare')
+    bufs = _inputs(B, L, 10)
+    topn = (ctypes.c_int * len(TOPN))(*TOPN)
+    out = torch.zeros(3 * len(TOPN) * 2, device='cuda')
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            _lib.check(lib.ultr_metrics_static(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), _lib.ptr(bufs[2]), 49, _lib.ptr(bufs[3]),
+                                               _lib.ptr(bufs[4]), B, L, topn, len(TOPN), 7, 4.0, _lib.ptr(out),
+                                               _lib.current_stream()), 'ultr_metrics_static (captured)')
+    ws = torch.zeros(lib.ultr_metrics_workspace_floats(B, len(TOPN)), device='cuda')
+    for seed in (11, 12):
+        for dst, src in zip(bufs, _inputs(B, L, seed)):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().copy()
+        assert np.array_equal(got, _call(False, B, L, seed, ws)), seed

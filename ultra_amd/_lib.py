@@ -104,6 +104,7 @@ SIGNATURES = {
     'ultr_metrics_workspace_floats': (_LL, [_I, _I]),
     'ultr_metrics': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
     'ultr_metrics_static_max_floats': (_LL, []),
+    'ultr_metrics_static_prepare': (_I, []),
     'ultr_metrics_static': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P]),
     'ultr_metrics_deferred': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F, _P, _P, _P]),
     'ultr_metrics_ties': (_I, [_P, _P, _P, _I, _P, _I, _I, ctypes.POINTER(ctypes.c_int), _I, _I, _F,

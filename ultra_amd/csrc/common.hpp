@@ -39,6 +39,25 @@ struct ProfScope {
 };
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) is a PER-DEVICE attribute: a process that
+// drives several GPUs must raise it on each.  One flag per (call site, device), relaxed atomics: the worst a race
+// between host threads does is set the attribute twice.
+struct PerDeviceOnce {
+  unsigned char done[64] = {};
+};
+static inline int raise_lds_limit(PerDeviceOnce& once, const void* kernel, int bytes, const char* who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev >= 0 && __atomic_load_n(&once.done[dev], __ATOMIC_RELAXED)) return ULTR_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: cannot raise the dynamic LDS limit to %d bytes", who, bytes);
+    return ULTR_EHIP;
+  }
+  if (dev >= 0) __atomic_store_n(&once.done[dev], (unsigned char)1, __ATOMIC_RELAXED);
+  return ULTR_OK;
+}
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------------------

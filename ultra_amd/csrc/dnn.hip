@@ -1694,15 +1694,9 @@ extern "C" int ultr_debug_stamps(long long* host, int n) {
 template <int WN, int WK, bool FUSE, bool GATHER, int QMAX, int RT = 1>
 static int launch_fwd_q(const FwdArgs& a, hipStream_t st, const char* name) {
   const size_t smem = sizeof(float) * fwd_smem_floats<WN, WK, RT>(a.K, FUSE);
-  static bool attr_set = false;  // the panel of a 512-wide layer is already past the 64 KB default
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX, RT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      set_error("ultr_dnn_forward: cannot raise the dynamic LDS limit");
-      return ULTR_EHIP;
-    }
-    attr_set = true;
-  }
+  static PerDeviceOnce attr_set;  // the panel of a 512-wide layer is already past the 64 KB default
+  if (const int rc_ = raise_lds_limit(attr_set, reinterpret_cast<const void*>(&fwd_layer_kernel<WN, WK, FUSE, GATHER, QMAX, RT>),
+                                      160 * 1024, "ultr_dnn_forward")) return rc_;
   ULTR_REQUIRE(smem <= 160 * 1024, ULTR_ELIMIT, "ultr_dnn_forward: layer needs %zu bytes of LDS", smem);
   if (ultr::g_profile_on)  // name the instantiation and the GEMM shape the way rocprofv3 sees the kernel
     name = ultr::profile_intern("%s<%d, %d, %s, %s, %d, %d>/K%dN%d", name, WN, WK, FUSE ? "true" : "false", GATHER ? "true" : "false",
@@ -1867,15 +1861,8 @@ extern "C" int ultr_dnn_forward(const UltrDnnDesc* desc, const float* params, co
 #ifdef ULTR_STAMPS
     { const char* e = getenv("ULTR_CHAIN_DBG"); c.dbg = e ? atoi(e) : 0; }
 #endif
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024) != hipSuccess) {
-        set_error("ultr_dnn_forward: cannot raise the dynamic LDS limit");
-        return ULTR_EHIP;
-      }
-      attr_done = true;
-    }
+    static PerDeviceOnce attr_done;
+    if (const int rc_ = raise_lds_limit(attr_done, reinterpret_cast<const void*>(fwd_chain_kernel), 160 * 1024, "ultr_dnn_forward")) return rc_;
     {
       ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("fwd_chain_kernel/P%lld", pw) : "fwd_chain_kernel", st);
       hipLaunchKernelGGL(fwd_chain_kernel, dim3((unsigned)cdiv(M, kChainRows)), dim3(kChainThreads), chain_smem, st, c);
@@ -2112,15 +2099,8 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
     if (smem > 160 * 1024) {
       use_chain = false;
     } else {
-      static bool attr_done = false;
-      if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess) {
-          set_error("ultr_dnn_backward: cannot raise the dynamic LDS limit");
-          return ULTR_EHIP;
-        }
-        attr_done = true;
-      }
+      static PerDeviceOnce attr_done;
+      if (const int rc_ = raise_lds_limit(attr_done, reinterpret_cast<const void*>(bwd_chain_kernel), 160 * 1024, "ultr_dnn_backward")) return rc_;
       {
         ultr::ProfScope prof_("bwd_chain_kernel", st);
         hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)cdiv(M, kChainRows)), dim3(kChainThreads), smem, st, c);

@@ -1172,15 +1172,8 @@ int launch_wgrad_all(int n_layers, const WgradArgs* layers, int nsplit, bool bf1
     pw += (long long)layers[j].K * layers[j].N;
   }
   g.start[n_layers] = start;
-  static bool wg_attr = false;
-  if (!wg_attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kWgRingBytes) != hipSuccess) {
-      set_error("wgrad_all_kernel: cannot raise the dynamic LDS limit");
-      return ULTR_EHIP;
-    }
-    wg_attr = true;
-  }
+  static PerDeviceOnce wg_attr;
+  if (const int rc_ = raise_lds_limit(wg_attr, reinterpret_cast<const void*>(wgrad_all_kernel), (int)kWgRingBytes, "wgrad_all_kernel")) return rc_;
   {
     ProfScope prof_(g_profile_on ? profile_intern(bf16 ? "wgrad_all_kernel_bf16/P%lld" : "wgrad_all_kernel/P%lld", pw)
                                  : "wgrad_all_kernel", st);
@@ -1221,15 +1214,9 @@ extern "C" long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int
 
 template <int RIDE, bool FAST, int NQ, bool BF>
 static int launch_chain3(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(train_chain_kernel<RIDE, FAST, NQ, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      set_error("ultr_dnn_train_fused: cannot raise the dynamic LDS limit");
-      return ULTR_EHIP;
-    }
-    attr_done = true;
-  }
+  static PerDeviceOnce attr_done;
+  if (const int rc_ = raise_lds_limit(attr_done, reinterpret_cast<const void*>(train_chain_kernel<RIDE, FAST, NQ, BF>), 160 * 1024,
+                                      "ultr_dnn_train_fused")) return rc_;
   long long pw = 0;
   for (int j = 0; j < a.H; ++j) pw += (long long)a.K[j] * a.N[j] + (j >= 1 ? (long long)a.K[j] * a.N[j] : 0);
   {
@@ -1276,9 +1263,9 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
                "ultr_dnn_train_fused: no loss request parked (call ultr_loss_*_deferred with the same scores first)");
   const float* pl_scores = pl.kind == ULTR_RIDE_DLA ? pl.dla.scores : pl.kind == ULTR_RIDE_IPW ? pl.ipw.scores
                            : pl.kind == ULTR_RIDE_REM ? pl.rem.scores : pl.pd.scores;
+  g_pending_loss.kind = ULTR_RIDE_NONE;  // consumed, also when it does not match (ultr_hip.h): it must not outlive its buffers
   ULTR_REQUIRE(pl_scores == scores && pl.rows() == M, ULTR_EINVAL,
                "ultr_dnn_train_fused: the parked loss request is for another scores buffer or batch shape");
-  g_pending_loss.kind = ULTR_RIDE_NONE;
   float* ws = reinterpret_cast<float*>(workspace);
   const int has_ln = desc->norm == ULTR_NORM_LAYER;
   hipStream_t st = as_stream(stream);
@@ -1452,11 +1439,7 @@ extern "C" int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, vo
     r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
   }
   TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}, AssembleArgs{}, 0, 0};
-  if (g_pending_assemble.on && g_pending_assemble.nblocks <= 4096) {  // the next batch's assembly rides with the update
-    o.a = g_pending_assemble.a;
-    o.a_blocks = (int)g_pending_assemble.nblocks; o.a_pad = (o.a_blocks + 7) & ~7;
-    g_pending_assemble.on = false;
-  }
+  // (a parked assembly of the next batch rides with the update: clip_adagrad_impl takes it once its checks have passed)
   float* wsf = reinterpret_cast<float*>(workspace);
   for (int j = P.bf16 ? 0 : 1; j < P.H; ++j) {
     const int t = o.tr.n++;
@@ -1465,5 +1448,5 @@ extern "C" int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, vo
     o.tr.pk[t] = P.bf16 ? reinterpret_cast<unsigned short*>(wsf + P.wp[j]) : nullptr;
     o.tr.pkt[t] = P.bf16 && j >= 1 ? reinterpret_cast<unsigned short*>(wsf + P.wtp[j]) : nullptr;
   }
-  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream);
+  return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream, true);
 }

@@ -411,12 +411,8 @@ static size_t metrics_smem(const MetricsArgs& a) {
 }
 
 int launch_metrics_now(const MetricsArgs& a, unsigned nblocks, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(metrics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              96 * 1024);
-    attr_set = true;
-  }
+  static PerDeviceOnce attr_set;
+  if (const int rc_ = raise_lds_limit(attr_set, reinterpret_cast<const void*>(metrics_kernel), 96 * 1024, "ultr_metrics")) return rc_;
   if (a.P <= 16 && a.B >= kLanesMinB) {  // one lane per list (nblocks was sized for it by prepare_metrics)
     ultr::ProfScope prof_("metrics_lanes_kernel", st);
     const bool err = (a.metric_mask & ULTR_METRIC_ERR) != 0, has_u = a.u_pred || a.tie_seed != 0ull;
@@ -502,21 +498,41 @@ constexpr int kMaxDevices = 64;
 static float* g_scratch_ptr[kMaxDevices] = {};
 static std::mutex g_scratch_mu;
 
-static int static_scratch(float** out) {
+// stream: the stream the caller is about to launch on, or nullptr when called from the set-up entry point.  The first
+// look-up on a device loads the code object's symbol table: that must not happen inside a graph capture, so a capturing
+// first call is refused (call ultr_metrics_static_prepare, or ultr_metrics_static itself once, before capturing).
+static int static_scratch(float** out, hipStream_t stream, bool have_stream) {
   int dev = -1;
   ULTR_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices, ULTR_EHIP,
                "ultr_metrics_static: no current device (or ordinal above %d)", kMaxDevices - 1);
-  std::lock_guard<std::mutex> lock(g_scratch_mu);
-  if (!g_scratch_ptr[dev]) {
-    void* p = nullptr;
-    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
-    ULTR_REQUIRE(e == hipSuccess && p, ULTR_EHIP, "ultr_metrics_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
-    g_scratch_ptr[dev] = static_cast<float*>(p);
+  float* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);  // set once per device, never changed afterwards
+  if (!p) {
+    if (have_stream) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+      ULTR_REQUIRE(cs == hipStreamCaptureStatusNone, ULTR_EINVAL,
+                   "ultr_metrics_static: first call on device %d inside a stream capture: call "
+                   "ultr_metrics_static_prepare() (or this function once) on that device before capturing", dev);
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    p = g_scratch_ptr[dev];
+    if (!p) {
+      void* q = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&q, HIP_SYMBOL(scratch));
+      ULTR_REQUIRE(e == hipSuccess && q, ULTR_EHIP, "ultr_metrics_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+      p = static_cast<float*>(q);
+      __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);
+    }
   }
-  *out = g_scratch_ptr[dev];
+  *out = p;
   return ULTR_OK;
 }
 }  // namespace ultr
+
+extern "C" int ultr_metrics_static_prepare(void) {
+  float* ws = nullptr;
+  return static_scratch(&ws, nullptr, false);
+}
 
 extern "C" long long ultr_metrics_static_max_floats(void) { return kStaticWsFloats; }
 
@@ -528,7 +544,7 @@ extern "C" int ultr_metrics_static(const float* scores, const float* labels, con
                "(use ultr_metrics with a workspace of your own)",
                B, n_topn, ultr_metrics_workspace_floats(B > 0 ? B : 1, n_topn), kStaticWsFloats);
   float* ws = nullptr;
-  int rc = static_scratch(&ws);
+  int rc = static_scratch(&ws, as_stream(stream), true);
   if (rc) return rc;
   MetricsArgs a;
   unsigned nblocks;

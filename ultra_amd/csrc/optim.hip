@@ -211,11 +211,25 @@ using namespace ultr;
 namespace ultr {
 int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom,
                       float scale_const, float l2, float clip_norm, float lr, int strategy, float* out_norm,
-                      float* ws, const SmallGroup& rider, TailOpts o, void* stream) {
+                      float* ws, const SmallGroup& rider, TailOpts o, void* stream, bool take_assemble) {
   ULTR_REQUIRE(theta && grads && n > 0, ULTR_EINVAL, "ultr_clip_adagrad: bad argument");
   ULTR_REQUIRE(strategy == ULTR_OPT_ADAGRAD || strategy == ULTR_OPT_SGD, ULTR_EINVAL,
                "ultr_clip_adagrad: grad_strategy=%d", strategy);
   ULTR_REQUIRE(strategy == ULTR_OPT_SGD || acc, ULTR_EINVAL, "ultr_clip_adagrad: Adagrad needs an accumulator");
+  // Every argument check comes before the parked requests (metric column sums, EM-state update, next batch's assembly)
+  // are taken: a call that fails its checks leaves them parked for the caller's next, corrected call or flush.
+  if (n <= 4096) {
+    ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0 && o.tr.n == 0 && !take_assemble, ULTR_EINVAL,
+                 "ultr_clip_adagrad: the fused options need a main group of more than 4096 parameters");
+  } else {
+    ULTR_REQUIRE(ws, ULTR_EINVAL, "ultr_clip_adagrad: workspace required");
+    ULTR_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grads % 16 == 0) && (!acc || (uintptr_t)acc % 16 == 0),
+                 ULTR_EINVAL, "ultr_clip_adagrad: buffers must be 16-byte aligned");
+    if (l2 != 0.f) o.sumsq = nullptr;  // the partials are of the raw gradient: with an l2 term the norm pass runs
+    ULTR_REQUIRE(!o.sumsq || (o.n_sumsq > 0 && o.n_covered >= 0 && o.n_covered <= n && n - o.n_covered <= 65536), ULTR_EINVAL,
+                 "ultr_clip_adagrad3: bad sum-of-squares partials (n_sumsq=%d n_covered=%lld)", o.n_sumsq, o.n_covered);
+    ULTR_REQUIRE(o.pub_n == 0 || (o.pub_src && o.pub_dst && o.pub_n > 0), ULTR_EINVAL, "ultr_clip_adagrad3: bad publish range");
+  }
   if (g_pending_mtail.on) {  // the column sums of the fused step's in-step metrics: carried likewise
     g_pending_mtail.on = false;
     if (n > 4096) {
@@ -235,8 +249,6 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
     }
   }
   if (n <= 4096) {
-    ULTR_REQUIRE(rider.n == 0 && !o.sumsq && o.pub_n == 0 && o.tr.n == 0 && o.a_blocks == 0, ULTR_EINVAL,
-                 "ultr_clip_adagrad: the fused options need a main group of more than 4096 parameters");
     {
       ultr::ProfScope prof_("clip_adagrad_small_kernel", as_stream(stream));
       hipLaunchKernelGGL(clip_adagrad_small_kernel, dim3(1), dim3(kOptThreads), 0, as_stream(stream), theta, acc, grads,
@@ -244,13 +256,11 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
     }
     return check_launch("clip_adagrad_small_kernel");
   }
-  ULTR_REQUIRE(ws, ULTR_EINVAL, "ultr_clip_adagrad: workspace required");
-  ULTR_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grads % 16 == 0) && (!acc || (uintptr_t)acc % 16 == 0),
-               ULTR_EINVAL, "ultr_clip_adagrad: buffers must be 16-byte aligned");
-  if (l2 != 0.f) o.sumsq = nullptr;  // the partials are of the raw gradient: with an l2 term the norm pass runs
-  ULTR_REQUIRE(!o.sumsq || (o.n_sumsq > 0 && o.n_covered >= 0 && o.n_covered <= n && n - o.n_covered <= 65536), ULTR_EINVAL,
-               "ultr_clip_adagrad3: bad sum-of-squares partials (n_sumsq=%d n_covered=%lld)", o.n_sumsq, o.n_covered);
-  ULTR_REQUIRE(o.pub_n == 0 || (o.pub_src && o.pub_dst && o.pub_n > 0), ULTR_EINVAL, "ultr_clip_adagrad3: bad publish range");
+  if (take_assemble && g_pending_assemble.on && g_pending_assemble.nblocks <= 4096) {  // the next batch's assembly rides along
+    o.a = g_pending_assemble.a;
+    o.a_blocks = (int)g_pending_assemble.nblocks; o.a_pad = (o.a_blocks + 7) & ~7;
+    g_pending_assemble.on = false;
+  }
   long long blocks = cdiv(n >> 2, kOptThreads);
   if (blocks > kOptMaxBlocks) blocks = kOptMaxBlocks;
   if (blocks < 1) blocks = 1;

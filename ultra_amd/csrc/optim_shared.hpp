@@ -63,6 +63,6 @@ struct TailOpts {
 
 int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom, float scale_const,
                       float l2, float clip_norm, float lr, int strategy, float* out_norm, float* ws, const SmallGroup& rider,
-                      TailOpts o, void* stream);
+                      TailOpts o, void* stream, bool take_assemble = false);
 
 }  // namespace ultr

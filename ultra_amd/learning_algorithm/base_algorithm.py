@@ -500,10 +500,18 @@ class BaseAlgorithm(ABC):
         return None, scores.t().contiguous().cpu().numpy(), data_utils.Summary(fetch=fetch)
 
     # ---- optimiser helper --------------------------------------------------------------------------
+    def _params_written_outside_fused(self, theta):
+        """An update call that does NOT refresh the fused step's streamed weight copies has written ``theta``: if that
+        is the scorer's parameter buffer the copies are stale from now on.  (The C calls write in place without
+        touching torch's version counter, so ``DNN.train_fused`` cannot see the write by itself.)"""
+        if theta is not None and theta.data_ptr() == self.model.params.data_ptr():
+            self.model._wt_state = None
+
     def _clip_adagrad(self, theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, out_norm):
         tail = getattr(self, '_tail', None)
         if tail is not None and n > 4096:
             return self._clip_adagrad3((theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, out_norm), None, tail)
+        self._params_written_outside_fused(theta)
         _lib.check(_lib.lib().ultr_clip_adagrad(
             _lib.ptr(theta), _lib.ptr(acc), _lib.ptr(grads), int(n), _lib.ptr(denom), float(scale_const), float(l2),
             float(clip_norm), float(lr), self.strategy, _lib.ptr(out_norm), _lib.ptr(self.opt_ws),
@@ -520,6 +528,8 @@ class BaseAlgorithm(ABC):
         if tail is not None:
             return self._clip_adagrad3(main, small, tail)
         (th, ac, gr, n, den, sc, l2, clip, lr, out), (ths, acs, grs, ns, dens, scs, l2s, clips, lrs, outs) = main, small
+        self._params_written_outside_fused(th)
+        self._params_written_outside_fused(ths)
         _lib.check(_lib.lib().ultr_clip_adagrad2(
             _lib.ptr(th), _lib.ptr(ac), _lib.ptr(gr), int(n), _lib.ptr(den), float(sc), float(l2), float(clip), float(lr),
             self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
@@ -551,6 +561,8 @@ class BaseAlgorithm(ABC):
             if pub:
                 tail['published'] = True
             return
+        self._params_written_outside_fused(th)
+        self._params_written_outside_fused(ths)
         _lib.check(_lib.lib().ultr_clip_adagrad3(
             _lib.ptr(th), _lib.ptr(ac), _lib.ptr(gr), int(n), _lib.ptr(den), float(sc), float(l2), float(clip), float(lr),
             self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
