@@ -93,7 +93,7 @@ def test_dla_steps_match_reference_graph(hp, B, F, mhp):
         t_in = torch_feed(data, batch)
         u = tie_uniforms(model, rng, B)
         loss, _, summary = model.step(None, feed_dict, False)
-        assert model._train_bufs['fused']  # lists of 10: the fused step is what is being compared
+        assert model._train_bufs['fused'] == model._fused_ok(batch)  # lists of 10: the fused step unless switched off
         ref_loss, ref_sum = ref.step(*t_in, u_pred=u)
         assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss), step
         got = summary.as_dict()

@@ -102,12 +102,18 @@ int main(int argc, char** argv) {
       if (c) printf("   last dgrad GEMM: %.0f shader cycles in %.0f ns per workgroup = %.2f GHz\n", cyc / c, wall / c, cyc / wall);
     }
     if (ultr_debug_tc_wstamps) {
-      std::vector<long long> ws((size_t)1024 * 32);
+      // per-wave stamps: forward layer j: 3j start of GEMM, 3j+1 GEMM + epilogue done, 3j+2 next input stage done;
+      // 8 output stage, 9 output backward, 10 / 11 dgrad_2 + row pass, 12 / 13 dgrad_1 + row pass
+      std::vector<long long> ws((size_t)1024 * 128);
       ultr_debug_tc_wstamps(ws.data(), (int)ws.size());
-      for (int w = 0; w < 8; ++w) {
-        double a = 0, b2 = 0, c2 = 0; int c = 0;
-        for (int b = 0; b < NB; ++b) { const long long* s = &ws[((size_t)b * 8 + w) * 4]; if (s[0] && s[1]) { a += (s[0] - t0) / 100.0; b2 += (s[1] - t0) / 100.0; c2 += (s[2] - t0) / 100.0; c++; } }
-        if (c) printf("   wave %d: last dgrad GEMM start %.2f end %.2f (%.2f us), row pass done %.2f\n", w, a / c, b2 / c, (b2 - a) / c, c2 / c);
+      for (int i = 0; i < 14; ++i) {
+        printf("   wstamp %2d:", i);
+        for (int w = 0; w < 8; ++w) {
+          double a = 0; int c = 0;
+          for (int b = 0; b < NB; ++b) { const long long v = ws[((size_t)b * 8 + w) * 16 + i]; if (v) { a += (v - t0) / 100.0; c++; } }
+          printf(" %6.2f", c ? a / c : 0.0);
+        }
+        printf("\n");
       }
     }
     double prev = 0;

@@ -26,10 +26,10 @@ constexpr int kTcMiscFloats = (ULTR_MAX_LAYERS + 1) * 32 + 32;  // row statistic
 
 #ifdef ULTR_STAMPS
 __device__ long long g_tc_stamps[1024 * 32];
-__device__ long long g_tc_wstamps[1024 * 8 * 4];
+__device__ long long g_tc_wstamps[1024 * 8 * 16];
 #define TC_WSTAMP(i)                                                                                                  \
   do {                                                                                                                \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_tc_wstamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (i)] = wall_clock64(); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_tc_wstamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64(); \
   } while (0)
 __device__ long long g_wg_stamps[1024 * 8];
 #define WG_STAMP(i)                                                                                        \
@@ -67,6 +67,8 @@ struct TcArgs {
   int dbg;
   DlaArgs dla; IpwArgs ipw; RemArgs rem; PdArgs pd;       // the one matching the kernel's RIDE is live
 };
+
+#define ULTR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 struct TcFrag { float4 b[4]; };
 
@@ -142,7 +144,10 @@ __device__ __forceinline__ void tc_wload(const TcGeo& g, int colc, unsigned voff
   // for the oldest chunk only.  Past the end of the stream (i >= nch) all lanes read the first 16 bytes of a row of
   // the matrix's first chunk: one cache line per load, nothing new from L2.
   const bool on = i < g.nch;  // wave-uniform
-  const int c = on ? g.c_begin + i : 0;
+  int c = on ? g.c_begin + i : 0;
+#ifdef ULTR_STAMPS
+  if (g.dbg & 2) c = g.c_begin;  // every chunk re-reads the wave's first one: L1 hits, no L2 traffic (timing only)
+#endif
   if (FAST || 16 * c + 16 <= g.K) {
     const float* rowp = g.W + (size_t)(16 * c) * g.ld;
     const unsigned vo = on ? voff : 0u;
@@ -159,9 +164,11 @@ __device__ __forceinline__ void tc_wload(const TcGeo& g, int colc, unsigned voff
 template <bool BF> __device__ __forceinline__ unsigned tc_voff(const TcGeo& g, int colc, int kk) {
   return BF ? (unsigned)(2 * (kk * g.ld + colc)) : (unsigned)(4 * kk * g.ld + colc);
 }
-template <bool FAST, bool BF>
+// ALWAYS: waves without a unit of their own request (clamped, in-bounds) chunks as well, so that the number of loads
+// this call puts in flight is the same on every path and a later wait for OLDER loads can be a counted one
+template <bool FAST, bool BF, bool ALWAYS = false>
 __device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcRing& R) {
-  if (g.u_first < g.U) {
+  if (ALWAYS || g.u_first < g.U) {
     const int colc = min(64 * g.u_first + 4 * nn, g.ld - 4);
     const unsigned voff = tc_voff<BF>(g, colc, kk);
 #pragma unroll
@@ -208,9 +215,18 @@ __device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcRi
 // multiplied out it serves as the split-K exchange buffer.  epi(u, acc) receives the finished unit:
 // acc[t][r] = out[row 4 kk + r][col 64 u + 4 nn + t].  The first three weight chunks of the wave's first unit must
 // already be in the ring (tc_prefetch).
+// vmcnt(0) through the builtin, which the compiler's wait-count pass models (an asm statement it would not): afterwards
+// it knows that every earlier load has landed.  Used where that is already true at run time -- at the end of a weight
+// stream, whose last chunk is younger than everything the following stage reads (gamma / beta / bias requested before
+// the GEMM) -- so that the stage's first use of those values does not get a conservative vmcnt(0) of its own, which would
+// ALSO wait for the next layer's prefetch issued in between (the counter is in-order): measured, that wait was most of
+// every stage (1 us each).
+__device__ __forceinline__ void tc_drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// bias: the layer's bias vector (forward epilogues; requested with the unit's first chunks) or nullptr
 template <bool FAST, bool BF, class Epi>
-__device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn, int kk, int lane, TcRing& R, Epi epi,
-                                        int stamp = -1) {
+__device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn, int kk, int lane, TcRing& R, const float* bias,
+                                        Epi epi, int stamp = -1) {
   if (stamp >= 0) TC_STAMP(stamp);
   const float* arow = A + nn * PS + 4 * kk + 16 * g.c_begin;
   for (int u = g.u_first; u < g.U; u += 8) {
@@ -223,6 +239,8 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
 #pragma unroll
       for (int i = 0; i < kTcStages - 1; ++i) tc_wload<FAST, BF>(g, colc, voff, i, kk, R.s[i]);
     }
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = *reinterpret_cast<const float4*>(bias + min(64 * u + 4 * nn, ((g.N + 3) & ~3) - 4));
     float4 a_cur = *reinterpret_cast<const float4*>(arow);
     auto compute = [&](TcFrag& S, int i) {
       // the panel values of the NEXT chunk are requested before this chunk's MFMAs: their LDS latency runs under them
@@ -237,6 +255,14 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
         return;
       }
       const float a[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#ifdef ULTR_STAMPS
+      if (g.dbg & 4) {  // no MFMA: the stream alone (timing only)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { acc[0][0] += S.b[s].x * a[s]; acc[1][0] += S.b[s].y; acc[2][0] += S.b[s].z; acc[3][0] += S.b[s].w; }
+        a_cur = a_nxt;
+        return;
+      }
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.b[s].x, acc[0], 0, 0, 0);
@@ -251,6 +277,7 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
     TC_STREAM(g.nch, TC_LOAD, TC_COMPUTE);
 #undef TC_LOAD
 #undef TC_COMPUTE
+    tc_drain_loads();
     if (stamp >= 0) TC_STAMP(stamp + 1);
     if (g.KS > 1) {  // uniform over the workgroup (U < 8: exactly one unit per wave)
       lds_barrier();  // the panel has been multiplied out: the exchange buffer takes its place
@@ -275,12 +302,13 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
       }
     }
     if (stamp >= 0) TC_STAMP(stamp + 4);
-    if (g.ks == 0) epi(u, acc);
+    if (g.ks == 0) epi(u, acc, b4);
   }
   if (g.u_first >= g.U && g.KS > 1) {  // idle waves of a non-power-of-two unit count still meet the barriers
     lds_barrier();
     lds_barrier();
   }
+  tc_drain_loads();  // on every path out of the GEMM (a wave without a unit has nothing in flight either)
 }
 
 // FAST kernels are compiled for the reference's default scorer (DNN.py:25-34: elu, layer normalisation) with every width a
@@ -303,6 +331,30 @@ template <bool FAST> __device__ __forceinline__ float tc_rsqrt(float v) {
 template <bool FAST> __device__ __forceinline__ bool tc_ok(int k, int e, int K) { return FAST ? k < K : k + e < K; }
 __device__ __forceinline__ void tc_unpack(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 
+// The stages between the GEMMs are chains of dependent instructions (LDS read -> two wave reductions -> normalise ->
+// store): a wave that owns TWO valid rows (w and w + 8; with lists of 10 that is waves 0 and 1) walks both chains in
+// lockstep, step by step, so that one row's latencies hide behind the other's -- the workgroup waits for its slowest
+// wave at the next barrier, and a wave that did its rows one after the other took twice as long as the rest.  Each
+// row's arithmetic is what it was (same operations, same order).
+template <int NR> struct TcRows { static constexpr int value = NR; };
+template <int NR> __device__ __forceinline__ void wave_sum_rows(float (&v)[NR]) {
+#define ULTR_TC_STEP(ctrl) { float t_[NR]; _Pragma("unroll") for (int r = 0; r < NR; ++r) t_[r] = ULTR_DPP_F(v[r], ctrl); \
+                             _Pragma("unroll") for (int r = 0; r < NR; ++r) v[r] += t_[r]; }
+  ULTR_TC_STEP(0xB1) ULTR_TC_STEP(0x4E) ULTR_TC_STEP(0x141) ULTR_TC_STEP(0x140)
+#undef ULTR_TC_STEP
+  {
+    float a[NR], o[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) a[r] = xor16_partner(v[r], &o[r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = a[r] + o[r];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) a[r] = xor32_partner(v[r], &o[r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = a[r] + o[r];
+  }
+}
+
 // NQ: float4 per lane and row the stages are compiled for (256 NQ >= the widest layer input, rounded up to 16)
 // BF: the hidden layers' GEMMs (forward and dgrad) multiply bf16-rounded activations with the packed bf16 weight copies,
 // accumulating in fp32; everything between the GEMMs (LayerNorm, activations, loss, the output layer) stays fp32.
@@ -322,6 +374,12 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   float* s_score = s_stat + (ULTR_MAX_LAYERS + 1) * 32;    // [16]
   TcRing R;
   TC_STAMP(0);
+#ifdef ULTR_TC_PRIO
+  // the two waves of a SIMD (w and w + 4) run the same program from the same barrier: left alone they reach their MFMA
+  // blocks and their load sections together, and the matrix pipe idles during the latter.  A static priority for the
+  // second half makes one of the pair win every arbitration, which staggers them
+  if (w >= 4) __builtin_amdgcn_s_setprio(ULTR_TC_PRIO);
+#endif
 
   // ---- the wave's two rows, w and w + 8 (valid rows spread evenly over the SIMDs): local row rr = li * L + l  <->
   // list list0 + li, rank l.  Rows beyond the workgroup's lists are skipped by every stage; their LDS rows only have
@@ -336,13 +394,43 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     re[r2] = rvalid[r2] ? (long long)l * B + b : 0;
     rm[r2] = rvalid[r2] ? b * L + l : 0;
   }
-  // ---- layer 0: weights first, then the rows (doc id -> table row + statistics: two dependent round trips)
-  TcGeo g = tc_geo(BF ? p.Wp[0] : p.W[0], p.K[0], p.N[0], p.ldn[0], w);
-  g.dbg = p.dbg;
-  tc_prefetch<FAST, BF>(g, nn, kk, R);
+  // ---- layer 0.  Everything the workgroup requests before its first GEMM, in the order the in-order load counter
+  // wants it: what a later wait needs first is requested first.  doc ids (the gather's first round trip), the loss
+  // operands and gamma / beta; then -- once the doc ids are here -- the gathered rows and their statistics (second round
+  // trip); only then the first weight chunks and the L2 warm-up touches, which nothing waits for before the GEMM.
   int docid[2];
 #pragma unroll
   for (int r2 = 0; r2 < 2; ++r2) docid[r2] = rvalid[r2] ? p.docids[re[r2]] : p.n_rows;
+  // ---- the lane's element of the loss: list list0 + lane / 16, rank lane % 16 (loads now, arithmetic later)
+  const int li_l = lane >> 4, r_l = lane & 15;
+  const long long b_l = list0 + li_l;
+  const bool live = li_l < nl && r_l < L && b_l < B;
+  const long long e_l = live ? (long long)r_l * B + b_l : 0;
+  float c_l = 0.f, wgt_l = 0.f, pd_tp = 1.f, pd_tm = 1.f, rem_bias = 0.f, rem_p = 1.f;
+  unsigned int rem_step = 0u;
+  float tower_w = 0.f, tower_b = 0.f, ipw_t = 0.f;  // operands of the loss constants formed under the first GEMM
+  if (RIDE == ULTR_RIDE_DLA) {
+    c_l = live ? p.dla.clicks[e_l] : 0.f;
+    tower_w = r_l < L ? p.dla.prop_params[r_l] : 0.f;
+    tower_b = p.dla.prop_params[L];
+  }
+  if (RIDE == ULTR_RIDE_IPW) {
+    c_l = live ? p.ipw.clicks[e_l] : 0.f;
+    if (!p.ipw.ipw_table) wgt_l = live ? p.ipw.pw[e_l] : 0.f;
+    else ipw_t = p.ipw.ipw_table[r_l < p.ipw.n_ipw ? r_l : p.ipw.n_ipw - 1];
+  }
+  if (RIDE == ULTR_RIDE_PD) {
+    c_l = live ? p.pd.clicks[e_l] : 0.f;
+    pd_tp = r_l < L ? p.pd.t_plus[r_l] : 1.f;
+    pd_tm = r_l < L ? p.pd.t_minus[r_l] : 1.f;
+  }
+  if (RIDE == ULTR_RIDE_REM) {
+    c_l = live ? p.rem.clicks[e_l] : 0.f;
+    rem_bias = p.rem.bias_ptr ? p.rem.bias_ptr[0] : 0.f;
+    rem_step = p.rem.step + (p.rem.step_ctr ? p.rem.step_ctr[0] : 0u);
+    rem_p = r_l < L ? p.rem.propensity[r_l] : 1.f;
+  }
+  const float ob = p.bias[H][0];  // the output layer's bias
   float4 gm[NQ], btq[NQ];  // gamma / beta of the coming input stage, this lane's columns
   {
     const int K = p.K[0], nq = (((K + 15) & ~15) + 255) >> 8, k_last4 = ((K + 3) & ~3) - 4;
@@ -357,52 +445,11 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
       }
     }
   }
-  // ---- the lane's element of the loss: list list0 + lane / 16, rank lane % 16 (loads now, arithmetic later)
-  const int li_l = lane >> 4, r_l = lane & 15;
-  const long long b_l = list0 + li_l;
-  const bool live = li_l < nl && r_l < L && b_l < B;
-  const long long e_l = live ? (long long)r_l * B + b_l : 0;
-  float c_l = 0.f, wgt_l = 0.f, pd_tp = 1.f, pd_tm = 1.f, rem_bias = 0.f, rem_p = 1.f;
-  unsigned int rem_step = 0u;
-  if (RIDE == ULTR_RIDE_DLA) c_l = live ? p.dla.clicks[e_l] : 0.f;
-  if (RIDE == ULTR_RIDE_IPW) {
-    c_l = live ? p.ipw.clicks[e_l] : 0.f;
-    if (!p.ipw.ipw_table) wgt_l = live ? p.ipw.pw[e_l] : 0.f;
-  }
-  if (RIDE == ULTR_RIDE_PD) {
-    c_l = live ? p.pd.clicks[e_l] : 0.f;
-    pd_tp = r_l < L ? p.pd.t_plus[r_l] : 1.f;
-    pd_tm = r_l < L ? p.pd.t_minus[r_l] : 1.f;
-  }
-  if (RIDE == ULTR_RIDE_REM) {
-    c_l = live ? p.rem.clicks[e_l] : 0.f;
-    rem_bias = p.rem.bias_ptr ? p.rem.bias_ptr[0] : 0.f;
-    rem_step = p.rem.step + (p.rem.step_ctr ? p.rem.step_ctr[0] : 0u);
-    rem_p = r_l < L ? p.rem.propensity[r_l] : 1.f;
-  }
-
-  // ---- L2 warm-up: every workgroup starts at once, so the FIRST touch of each weight line would otherwise be paid
-  // by all of them together, layer by layer, at HBM / Infinity-Cache latency in the middle of a GEMM.  The 32
-  // workgroups that (by the round-robin placement; speed only) share an XCD each touch a slice of the later layers'
-  // weights now, while the gather's round trips are in flight.
-  float warm = 0.f;
-  {
-    const int xi = blockIdx.x >> 3, nx = (gridDim.x + 7) >> 3;
-    for (int j = 0; j < H; ++j) {
-      // floats of the streamed copy: the fp32 matrix, or half as many for the packed bf16 one (rows padded to 16)
-      const long long tot = BF ? (long long)((p.K[j] + 15) & ~15) * p.ldn[j] / 2 : (long long)p.K[j] * p.ldn[j];
-      const long long totT = j < 1 ? 0 : BF ? (long long)((p.N[j] + 15) & ~15) * ((p.K[j] + 3) & ~3) / 2
-                                            : (long long)p.N[j] * ((p.K[j] + 3) & ~3);
-      const long long lines = (tot + 31) >> 5, linesT = (totT + 31) >> 5;
-      const long long per = (lines + nx - 1) / nx, perT = (linesT + nx - 1) / nx;
-      const float* wj = BF ? p.Wp[j] : p.W[j];
-      const float* wtj = BF ? p.WTp[j] : p.WT[j];
-      for (long long i = xi * per + tid; i < min((xi + 1) * per, lines); i += kTcThreads) warm += wj[i * 32];
-      for (long long i = xi * perT + tid; i < min((xi + 1) * perT, linesT); i += kTcThreads) warm += wtj[i * 32];
-    }
-  }
+  TcGeo g = tc_geo(BF ? p.Wp[0] : p.W[0], p.K[0], p.N[0], p.ldn[0], w);
+  g.dbg = p.dbg;
 
   // ---- input stage of layer 0: gathered rows, normalised with the table's statistics
+  float warm[2] = {0.f, 0.f};
   {
     const int K = p.K[0], K16 = (K + 15) & ~15, nq = (K16 + 255) >> 8, ldxh = (K + 3) & ~3;
     float4 x[2][NQ];
@@ -421,6 +468,47 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         if (q < nq) x[r2][q] = *reinterpret_cast<const float4*>(src + min(4 * lane + 256 * q, p.ldx - 4));
+    }
+    // the first weight chunks, behind the rows in the load queue
+    tc_prefetch<FAST, BF, true>(g, nn, kk, R);
+    // ---- L2 warm-up: every workgroup starts at once, so the FIRST touch of each weight line would otherwise be paid
+    // by all of them together, layer by layer, at HBM / Infinity-Cache latency in the middle of a GEMM.  The
+    // workgroups that (by the round-robin placement; speed only) share an XCD each touch a slice of the streamed
+    // matrices now: one or two lines per thread, no loop and no use of the values before the kernel's end, so that no
+    // wait stands between these requests and the gather (a `sum += load` loop here waited for every touch in turn).
+    {
+      const int xi = blockIdx.x >> 3, nx = (gridDim.x + 7) >> 3;
+      long long tot_lines = 0;
+      for (int j = 0; j < H; ++j) {
+        const long long tot = BF ? (long long)((p.K[j] + 15) & ~15) * p.ldn[j] / 2 : (long long)p.K[j] * p.ldn[j];
+        const long long totT = j < 1 ? 0 : BF ? (long long)((p.N[j] + 15) & ~15) * ((p.K[j] + 3) & ~3) / 2
+                                              : (long long)p.N[j] * ((p.K[j] + 3) & ~3);
+        tot_lines += ((tot + 31) >> 5) + ((totT + 31) >> 5);
+      }
+      const long long per = (tot_lines + nx - 1) / nx;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const long long rel = tid + kTcThreads * r;
+        long long line = xi * per + rel;
+        const float* src = nullptr;
+        if (rel >= per || line >= tot_lines) line = 0;  // nothing left to touch: the first line again (every lane issues)
+        {
+          for (int j = 0; j < H; ++j) {
+            const long long tot = BF ? (long long)((p.K[j] + 15) & ~15) * p.ldn[j] / 2 : (long long)p.K[j] * p.ldn[j];
+            const long long totT = j < 1 ? 0 : BF ? (long long)((p.N[j] + 15) & ~15) * ((p.K[j] + 3) & ~3) / 2
+                                                  : (long long)p.N[j] * ((p.K[j] + 3) & ~3);
+            const long long lines = (tot + 31) >> 5, linesT = (totT + 31) >> 5;
+            if (!src && line < lines) src = (BF ? p.Wp[j] : p.W[j]) + line * 32;
+            line -= lines;
+            if (!src && line >= 0 && line < linesT) src = (BF ? p.WTp[j] : p.WT[j]) + line * 32;
+            line -= linesT;
+          }
+        }
+        // (an LDS-DMA touch would need no register, but the compiler orders every later LDS access behind it with a
+        // vmcnt(0), which also waits for the weight chunks just requested)
+        if (!src) src = BF ? p.Wp[0] : p.W[0];
+        warm[r] = *src;
+      }
     }
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
@@ -454,8 +542,8 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     const int N = p.N[j];
     lds_barrier();  // the input panel is complete
     if (j == 0) {   // the loss constants' arithmetic, off the gather's critical path
-      if (RIDE == ULTR_RIDE_DLA) wgt_l = dla_tower(p.dla.prop_params, L, r_l, p.dla.prob_kind, p.dla.max_pw).pw;
-      if (RIDE == ULTR_RIDE_IPW && p.ipw.ipw_table) wgt_l = live ? ipw_weight(p.ipw, e_l, r_l, c_l) : 0.f;
+      if (RIDE == ULTR_RIDE_DLA) wgt_l = dla_tower_regs(tower_w, tower_b, L, r_l, p.dla.prob_kind, p.dla.max_pw).pw;
+      if (RIDE == ULTR_RIDE_IPW && p.ipw.ipw_table) wgt_l = live && c_l > 0.f ? ipw_t : 0.f;  // ipw_weight()
     }
     // gamma / beta of the NEXT input stage and this layer's bias ride along with the weight stream
     {
@@ -477,10 +565,10 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     float* actj = smem + p.act_off[j];
     const int aps = p.act_ps[j];
     const float* biasj = p.bias[j];
-    tc_gemm<FAST, BF>(g, P1, PS, nn, kk, lane, R, [&](int u, f32x4 (&acc)[4]) {
+    TC_WSTAMP(3 * j);
+    tc_gemm<FAST, BF>(g, P1, PS, nn, kk, lane, R, biasj, [&](int u, f32x4 (&acc)[4], const float4& b4) {
       const int col0 = 64 * u + 4 * nn;
       const int n16 = (N + 15) & ~15;
-      const float4 b4 = *reinterpret_cast<const float4*>(biasj + min(col0, ((N + 3) & ~3) - 4));
       if (col0 < n16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -494,6 +582,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
       }
     }, j == 2 ? 10 : -1);
     TC_STAMP(2 + 3 * j);
+    TC_WSTAMP(3 * j + 1);
     if (j + 1 < H) {  // the next layer's weight stream starts before its rows are normalised
       g = tc_geo(BF ? p.Wp[j + 1] : p.W[j + 1], p.K[j + 1], p.N[j + 1], p.ldn[j + 1], w);
       g.dbg = p.dbg;
@@ -506,63 +595,84 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     // ---- input stage of layer j + 1: LayerNorm of the activations -> panel (and xhat to memory for the weight gradients)
     {
       const int K = N, K16 = (K + 15) & ~15, nq = (K16 + 255) >> 8, ldxh = (K + 3) & ~3;
+      auto ln_rows = [&](auto nrc) {
+        constexpr int NR = decltype(nrc)::value;
+        float4 x[NR][NQ];
 #pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        if (!rvalid[r2]) continue;  // wave-uniform
-        const int row = w + 8 * r2;
-        float4 x[NQ];
+        for (int r2 = 0; r2 < NR; ++r2)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q < nq) x[q] = *reinterpret_cast<const float4*>(actj + row * aps + min(4 * lane + 256 * q, K16 - 4));
-        float mean = 0.f, rstd = 1.f;
+          for (int q = 0; q < NQ; ++q)
+            if (q < nq) x[r2][q] = *reinterpret_cast<const float4*>(actj + (w + 8 * r2) * aps + min(4 * lane + 256 * q, K16 - 4));
+        float mean[NR], rstd[NR];
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) { mean[r2] = 0.f; rstd[r2] = 1.f; }
         if (has_ln) {  // two-pass statistics (biased variance, keras LayerNormalization)
-          float sm = 0.f;
+          float sm[NR], m2[NR];
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (q < nq) {
-              const int k = 4 * lane + 256 * q;
-              float xs[4];
-              tc_unpack(x[q], xs);
+          for (int r2 = 0; r2 < NR; ++r2) {
+            sm[r2] = 0.f;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) sm += tc_ok<FAST>(k, e, K) ? xs[e] : 0.f;
-            }
-          mean = wave_sum(sm) * (1.f / (float)K);
-          float m2 = 0.f;
+            for (int q = 0; q < NQ; ++q)
+              if (q < nq) {
+                const int k = 4 * lane + 256 * q;
+                float xs[4];
+                tc_unpack(x[r2][q], xs);
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (q < nq) {
-              const int k = 4 * lane + 256 * q;
-              float xs[4];
-              tc_unpack(x[q], xs);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float dd = tc_ok<FAST>(k, e, K) ? xs[e] - mean : 0.f;
-                m2 = fmaf(dd, dd, m2);
+                for (int e = 0; e < 4; ++e) sm[r2] += tc_ok<FAST>(k, e, K) ? xs[e] : 0.f;
               }
-            }
-          rstd = tc_rsqrt<FAST>(wave_sum(m2) * (1.f / (float)K) + p.eps);
-          if (lane == 0) *reinterpret_cast<float2*>(s_stat + ((j + 1) * 16 + row) * 2) = make_float2(mean, rstd);
+          }
+          wave_sum_rows<NR>(sm);
+#pragma unroll
+          for (int r2 = 0; r2 < NR; ++r2) {
+            mean[r2] = sm[r2] * (1.f / (float)K);
+            m2[r2] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              if (q < nq) {
+                const int k = 4 * lane + 256 * q;
+                float xs[4];
+                tc_unpack(x[r2][q], xs);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float dd = tc_ok<FAST>(k, e, K) ? xs[e] - mean[r2] : 0.f;
+                  m2[r2] = fmaf(dd, dd, m2[r2]);
+                }
+              }
+          }
+          wave_sum_rows<NR>(m2);
+#pragma unroll
+          for (int r2 = 0; r2 < NR; ++r2) {
+            rstd[r2] = tc_rsqrt<FAST>(m2[r2] * (1.f / (float)K) + p.eps);
+            if (lane == 0) *reinterpret_cast<float2*>(s_stat + ((j + 1) * 16 + w + 8 * r2) * 2) = make_float2(mean[r2], rstd[r2]);
+          }
         }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q < nq) {
-            const int k = 4 * lane + 256 * q;
-            float xs[4], gg[4], bb[4], xh[4], a[4];
-            tc_unpack(x[q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb);
+        for (int r2 = 0; r2 < NR; ++r2) {
+          const int row = w + 8 * r2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bool ok = tc_ok<FAST>(k, e, K);
-              xh[e] = ok ? (xs[e] - mean) * rstd : 0.f;
-              a[e] = ok ? fmaf(xh[e], gg[e], bb[e]) : 0.f;
+          for (int q = 0; q < NQ; ++q)
+            if (q < nq) {
+              const int k = 4 * lane + 256 * q;
+              float xs[4], gg[4], bb[4], xh[4], a[4];
+              tc_unpack(x[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const bool ok = tc_ok<FAST>(k, e, K);
+                xh[e] = ok ? (xs[e] - mean[r2]) * rstd[r2] : 0.f;
+                a[e] = ok ? fmaf(xh[e], gg[e], bb[e]) : 0.f;
+              }
+              if (k < K16) {
+                *reinterpret_cast<float4*>(P1 + row * PS + k) = make_float4(a[0], a[1], a[2], a[3]);
+                if (k < ldxh) *reinterpret_cast<float4*>(p.xhat[j + 1] + rm[r2] * ldxh + k) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+              }
             }
-            if (k < K16) {
-              *reinterpret_cast<float4*>(P1 + row * PS + k) = make_float4(a[0], a[1], a[2], a[3]);
-              if (k < ldxh) *reinterpret_cast<float4*>(p.xhat[j + 1] + rm[r2] * ldxh + k) = make_float4(xh[0], xh[1], xh[2], xh[3]);
-            }
-          }
-      }
+        }
+      };
+      if (rvalid[1]) ln_rows(TcRows<2>{});       // wave-uniform (row w + 8 valid implies row w valid)
+      else if (rvalid[0]) ln_rows(TcRows<1>{});
     }
     TC_STAMP(4 + 3 * j);
+    TC_WSTAMP(3 * j + 2);
   }
 
   // ================================ output layer, loss, output-layer backward ================================
@@ -572,62 +682,82 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   {
     const float* actl = smem + p.act_off[H - 1];
     const int aps = p.act_ps[H - 1];
-    const float ob = p.bias[H][0];
+    auto out_rows = [&](auto nrc) {
+      constexpr int NR = decltype(nrc)::value;
 #pragma unroll
-    for (int r2 = 0; r2 < 2; ++r2) {
-      if (!rvalid[r2]) continue;
-      const int row = w + 8 * r2;
+      for (int r2 = 0; r2 < NR; ++r2)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (q < nqo) xo[r2][q] = *reinterpret_cast<const float4*>(actl + row * aps + min(4 * lane + 256 * q, Ko16 - 4));
+        for (int q = 0; q < NQ; ++q)
+          if (q < nqo) xo[r2][q] = *reinterpret_cast<const float4*>(actl + (w + 8 * r2) * aps + min(4 * lane + 256 * q, Ko16 - 4));
       if (has_ln) {
-        float sm = 0.f;
+        float sm[NR], m2[NR];
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) {
+          sm[r2] = 0.f;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < nqo) {
+              const int k = 4 * lane + 256 * q;
+              float xs[4];
+              tc_unpack(xo[r2][q], xs);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sm[r2] += tc_ok<FAST>(k, e, Ko) ? xs[e] : 0.f;
+            }
+        }
+        wave_sum_rows<NR>(sm);
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) {
+          mean[r2] = sm[r2] * (1.f / (float)Ko);
+          m2[r2] = 0.f;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < nqo) {
+              const int k = 4 * lane + 256 * q;
+              float xs[4];
+              tc_unpack(xo[r2][q], xs);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float dd = tc_ok<FAST>(k, e, Ko) ? xs[e] - mean[r2] : 0.f;
+                m2[r2] = fmaf(dd, dd, m2[r2]);
+              }
+            }
+        }
+        wave_sum_rows<NR>(m2);
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) rstd[r2] = tc_rsqrt<FAST>(m2[r2] * (1.f / (float)Ko) + p.eps);
+      }
+      float dot[NR];
+#pragma unroll
+      for (int r2 = 0; r2 < NR; ++r2) {
+        dot[r2] = 0.f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
           if (q < nqo) {
             const int k = 4 * lane + 256 * q;
-            float xs[4];
-            tc_unpack(xo[r2][q], xs);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sm += tc_ok<FAST>(k, e, Ko) ? xs[e] : 0.f;
-          }
-        mean[r2] = wave_sum(sm) * (1.f / (float)Ko);
-        float m2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q < nqo) {
-            const int k = 4 * lane + 256 * q;
-            float xs[4];
-            tc_unpack(xo[r2][q], xs);
+            float xs[4], gg[4], bb[4], ww[4];
+            tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb); tc_unpack(woq[q], ww);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float dd = tc_ok<FAST>(k, e, Ko) ? xs[e] - mean[r2] : 0.f;
-              m2 = fmaf(dd, dd, m2);
+              const float a = tc_ok<FAST>(k, e, Ko) ? fmaf((xs[e] - mean[r2]) * rstd[r2], gg[e], bb[e]) : 0.f;
+              dot[r2] = fmaf(a, ww[e], dot[r2]);
             }
           }
-        rstd[r2] = tc_rsqrt<FAST>(wave_sum(m2) * (1.f / (float)Ko) + p.eps);
       }
-      float dot = 0.f;
+      wave_sum_rows<NR>(dot);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (q < nqo) {
-          const int k = 4 * lane + 256 * q;
-          float xs[4], gg[4], bb[4], ww[4];
-          tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb); tc_unpack(woq[q], ww);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = tc_ok<FAST>(k, e, Ko) ? fmaf((xs[e] - mean[r2]) * rstd[r2], gg[e], bb[e]) : 0.f;
-            dot = fmaf(a, ww[e], dot);
-          }
+      for (int r2 = 0; r2 < NR; ++r2) {
+        const float sc = dot[r2] + ob;
+        if (lane == 0) {
+          s_score[w + 8 * r2] = sc;
+          p.scores[re[r2]] = sc;
         }
-      const float sc = wave_sum(dot) + ob;
-      if (lane == 0) {
-        s_score[row] = sc;
-        p.scores[re[r2]] = sc;
       }
-    }
+    };
+    if (rvalid[1]) out_rows(TcRows<2>{});
+    else if (rvalid[0]) out_rows(TcRows<1>{});
   }
   TC_STAMP(16);
+  TC_WSTAMP(8);
   lds_barrier();
 
   // ---- d_score of the lane's (list, rank), every wave for itself; the wave then picks the values of its two rows
@@ -672,57 +802,70 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e) aW[q][e] = aG[q][e] = aB[q][e] = 0.f;
+    auto outbwd_rows = [&](auto nrc) {
+      constexpr int NR = decltype(nrc)::value;
+      float s1[NR], s2[NR];
 #pragma unroll
-    for (int r2 = 0; r2 < 2; ++r2) {
-      if (!rvalid[r2]) continue;
-      const int row = w + 8 * r2;
-      float s1 = 0.f, s2 = 0.f;
+      for (int r2 = 0; r2 < NR; ++r2) s1[r2] = s2[r2] = 0.f;
       if (has_ln) {
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < nqo) {
+              const int k = 4 * lane + 256 * q;
+              float xs[4], gg[4], ww[4];
+              tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(woq[q], ww);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float gwg = tc_ok<FAST>(k, e, Ko) ? go[r2] * ww[e] * gg[e] : 0.f;
+                s1[r2] += gwg;
+                s2[r2] = fmaf(gwg, (xs[e] - mean[r2]) * rstd[r2], s2[r2]);
+              }
+            }
+        wave_sum_rows<NR>(s1);
+        wave_sum_rows<NR>(s2);
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) {
+          s1[r2] *= (1.f / (float)Ko);
+          s2[r2] *= (1.f / (float)Ko);
+        }
+      }
+#pragma unroll
+      for (int r2 = 0; r2 < NR; ++r2) {
+        const int row = w + 8 * r2;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
           if (q < nqo) {
             const int k = 4 * lane + 256 * q;
-            float xs[4], gg[4], ww[4];
-            tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(woq[q], ww);
+            float xs[4], gg[4], bb[4], ww[4], o4[4];
+            tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb); tc_unpack(woq[q], ww);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float gwg = tc_ok<FAST>(k, e, Ko) ? go[r2] * ww[e] * gg[e] : 0.f;
-              s1 += gwg;
-              s2 = fmaf(gwg, (xs[e] - mean[r2]) * rstd[r2], s2);
+              const bool ok = tc_ok<FAST>(k, e, Ko);
+              const float gw = ok ? go[r2] * ww[e] : 0.f;
+              float dx = gw;
+              if (has_ln) {
+                const float xh = (xs[e] - mean[r2]) * rstd[r2];
+                aW[q][e] += ok ? fmaf(gg[e], xh, bb[e]) * go[r2] : 0.f;
+                aG[q][e] = fmaf(gw, xh, aG[q][e]);
+                aB[q][e] += gw;
+                dx = rstd[r2] * (gw * gg[e] - s1[r2] - xh * s2[r2]);
+              } else {
+                aW[q][e] += ok ? xs[e] * go[r2] : 0.f;
+              }
+              o4[e] = ok ? dx * tc_actg<FAST>(act, xs[e]) : 0.f;
+            }
+            if (k < Ko16) {
+              const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
+              *reinterpret_cast<float4*>(P1 + row * PS + k) = ov;
+              if (k < ldz) *reinterpret_cast<float4*>(p.dz[H - 1] + rm[r2] * ldz + k) = ov;
             }
           }
-        s1 = wave_sum(s1) * (1.f / (float)Ko);
-        s2 = wave_sum(s2) * (1.f / (float)Ko);
       }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (q < nqo) {
-          const int k = 4 * lane + 256 * q;
-          float xs[4], gg[4], bb[4], ww[4], o4[4];
-          tc_unpack(xo[r2][q], xs); tc_unpack(gm[q], gg); tc_unpack(btq[q], bb); tc_unpack(woq[q], ww);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool ok = tc_ok<FAST>(k, e, Ko);
-            const float gw = ok ? go[r2] * ww[e] : 0.f;
-            float dx = gw;
-            if (has_ln) {
-              const float xh = (xs[e] - mean[r2]) * rstd[r2];
-              aW[q][e] += ok ? fmaf(gg[e], xh, bb[e]) * go[r2] : 0.f;
-              aG[q][e] = fmaf(gw, xh, aG[q][e]);
-              aB[q][e] += gw;
-              dx = rstd[r2] * (gw * gg[e] - s1 - xh * s2);
-            } else {
-              aW[q][e] += ok ? xs[e] * go[r2] : 0.f;
-            }
-            o4[e] = ok ? dx * tc_actg<FAST>(act, xs[e]) : 0.f;
-          }
-          if (k < Ko16) {
-            const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
-            *reinterpret_cast<float4*>(P1 + row * PS + k) = ov;
-            if (k < ldz) *reinterpret_cast<float4*>(p.dz[H - 1] + rm[r2] * ldz + k) = ov;
-          }
-        }
-    }
+    };
+    if (rvalid[1]) outbwd_rows(TcRows<2>{});
+    else if (rvalid[0]) outbwd_rows(TcRows<1>{});
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (q < nqo) {
@@ -746,6 +889,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     tc_prefetch<FAST, BF>(g, nn, kk, R);
   }
   TC_STAMP(17);
+  TC_WSTAMP(9);
   lds_barrier();
   {
     float* out = p.outpart + (long long)blockIdx.x * (3 * Ko + 4);
@@ -776,8 +920,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
 #ifdef ULTR_STAMPS
     if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memtime();
 #endif
-    if (j == 1) TC_WSTAMP(0);
-    tc_gemm<FAST, BF>(g, cur, PS, nn, kk, lane, R, [&](int u, f32x4 (&acc)[4]) {
+    tc_gemm<FAST, BF>(g, cur, PS, nn, kk, lane, R, nullptr, [&](int u, f32x4 (&acc)[4], const float4&) {
       const int col0 = 64 * u + 4 * nn;
       if (col0 < K16) {
 #pragma unroll
@@ -793,72 +936,90 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
 #ifdef ULTR_STAMPS
     if (j == 1 && threadIdx.x == 0 && blockIdx.x < 1024) g_tc_stamps[blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memtime();
 #endif
-    if (j == 1) TC_WSTAMP(1);
+    TC_WSTAMP(j == 1 ? 12 : 10);
     TC_STAMP(19 + 2 * (H - 1 - j));
     lds_barrier();
     {
       const float* acts = smem + p.act_off[j - 1];
       const int aps = p.act_ps[j - 1];
+      auto rowpass_rows = [&](auto nrc) {
+        constexpr int NR = decltype(nrc)::value;
+        float4 d4[NR][NQ], h4[NR][NQ];
 #pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        if (!rvalid[r2]) continue;
-        const int row = w + 8 * r2;
-        float4 d4[NQ], h4[NQ];
+        for (int r2 = 0; r2 < NR; ++r2)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q < nq) {
-            const int kc = min(4 * lane + 256 * q, K16 - 4);
-            d4[q] = *reinterpret_cast<const float4*>(nxt + row * PS + kc);
-            h4[q] = *reinterpret_cast<const float4*>(acts + row * aps + kc);
-          }
-        float mu = 0.f, rs = 1.f, c1 = 0.f, c2 = 0.f;
+          for (int q = 0; q < NQ; ++q)
+            if (q < nq) {
+              const int kc = min(4 * lane + 256 * q, K16 - 4);
+              d4[r2][q] = *reinterpret_cast<const float4*>(nxt + (w + 8 * r2) * PS + kc);
+              h4[r2][q] = *reinterpret_cast<const float4*>(acts + (w + 8 * r2) * aps + kc);
+            }
+        float mu[NR], rs[NR], c1[NR], c2[NR];
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) { mu[r2] = 0.f; rs[r2] = 1.f; c1[r2] = c2[r2] = 0.f; }
         if (has_ln) {
-          const float2 st = *reinterpret_cast<const float2*>(s_stat + (j * 16 + row) * 2);
-          mu = st.x;
-          rs = st.y;
+#pragma unroll
+          for (int r2 = 0; r2 < NR; ++r2) {
+            const float2 st = *reinterpret_cast<const float2*>(s_stat + (j * 16 + w + 8 * r2) * 2);
+            mu[r2] = st.x;
+            rs[r2] = st.y;
+          }
+#pragma unroll
+          for (int r2 = 0; r2 < NR; ++r2)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              if (q < nq) {
+                const int k = 4 * lane + 256 * q;
+                float dd[4], gg[4], hh[4];
+                tc_unpack(d4[r2][q], dd); tc_unpack(gm[q], gg); tc_unpack(h4[r2][q], hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float gv = tc_ok<FAST>(k, e, K) ? dd[e] * gg[e] : 0.f;
+                  c1[r2] += gv;
+                  c2[r2] = fmaf(gv, (hh[e] - mu[r2]) * rs[r2], c2[r2]);
+                }
+              }
+          wave_sum_rows<NR>(c1);
+          wave_sum_rows<NR>(c2);
+#pragma unroll
+          for (int r2 = 0; r2 < NR; ++r2) {
+            c1[r2] *= (1.f / (float)K);
+            c2[r2] *= (1.f / (float)K);
+          }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) {
+          const int row = w + 8 * r2;
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
             if (q < nq) {
               const int k = 4 * lane + 256 * q;
-              float dd[4], gg[4], hh[4];
-              tc_unpack(d4[q], dd); tc_unpack(gm[q], gg); tc_unpack(h4[q], hh);
+              float dd[4], gg[4], hh[4], o4[4];
+              tc_unpack(d4[r2][q], dd); tc_unpack(gm[q], gg); tc_unpack(h4[r2][q], hh);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float gv = tc_ok<FAST>(k, e, K) ? dd[e] * gg[e] : 0.f;
-                c1 += gv;
-                c2 = fmaf(gv, (hh[e] - mu) * rs, c2);
+                float dx = dd[e];
+                if (has_ln) dx = rs[r2] * (dx * gg[e] - c1[r2] - (hh[e] - mu[r2]) * rs[r2] * c2[r2]);
+                o4[e] = tc_ok<FAST>(k, e, K) ? dx * tc_actg<FAST>(act, hh[e]) : 0.f;
+              }
+              if (k < K16) {
+                const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                if (j >= 2) *reinterpret_cast<float4*>(nxt + row * PS + k) = ov;
+                if (k < ldo) *reinterpret_cast<float4*>(p.dz[j - 1] + rm[r2] * ldo + k) = ov;
               }
             }
-          c1 = wave_sum(c1) * (1.f / (float)K);
-          c2 = wave_sum(c2) * (1.f / (float)K);
         }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q < nq) {
-            const int k = 4 * lane + 256 * q;
-            float dd[4], gg[4], hh[4], o4[4];
-            tc_unpack(d4[q], dd); tc_unpack(gm[q], gg); tc_unpack(h4[q], hh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float dx = dd[e];
-              if (has_ln) dx = rs * (dx * gg[e] - c1 - (hh[e] - mu) * rs * c2);
-              o4[e] = tc_ok<FAST>(k, e, K) ? dx * tc_actg<FAST>(act, hh[e]) : 0.f;
-            }
-            if (k < K16) {
-              const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
-              if (j >= 2) *reinterpret_cast<float4*>(nxt + row * PS + k) = ov;
-              if (k < ldo) *reinterpret_cast<float4*>(p.dz[j - 1] + rm[r2] * ldo + k) = ov;
-            }
-          }
-      }
+      };
+      if (rvalid[1]) rowpass_rows(TcRows<2>{});
+      else if (rvalid[0]) rowpass_rows(TcRows<1>{});
     }
-    if (j == 1) TC_WSTAMP(2);
+    TC_WSTAMP(j == 1 ? 13 : 11);
     TC_STAMP(20 + 2 * (H - 1 - j));
     if (j >= 2) lds_barrier();
     cur_is_p1 ^= 1;
   }
   TC_STAMP(31);
-  if (warm == 1.2345e-30f && p.B < 0) p.outpart[0] = warm;  // never true: keeps the warm-up loads alive
+  if (warm[0] + warm[1] == 1.2345e-30f && p.B < 0) p.outpart[0] = warm[0];  // never true: keeps the warm-up loads alive
 }
 
 // WT_j[n][k] = W_j[k][n] for the hidden layers j >= 1 (32 x 32 tiles through LDS), one launch for all of them: the
@@ -919,7 +1080,6 @@ constexpr int kWgTile = 32 * 64;               // floats per operand tile
 constexpr int kWgSlot = 2 * kWgTile;           // A then B
 constexpr size_t kWgRingBytes = sizeof(float) * kWgStages * kWgSlot;
 
-#define ULTR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // BF (the bf16 step): the same ring of fp32 tiles; the operands are rounded to bf16 on their way from LDS to the
 // registers and multiplied by v_mfma_f32_32x32x16_bf16 (two per 32-row chunk instead of sixteen fp32 MFMAs), fp32 accumulate.
@@ -1193,7 +1353,7 @@ extern "C" int ultr_debug_wg_stamps(long long* host, int n) {
   return n;
 }
 extern "C" int ultr_debug_tc_wstamps(long long* host, int n) {
-  if (n > 1024 * 32) n = 1024 * 32;
+  if (n > 1024 * 128) n = 1024 * 128;
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tc_wstamps), sizeof(long long) * (size_t)n);
   return n;

@@ -96,11 +96,12 @@ struct DlaArgs {
 // The propensity tower at rank r = lane & 15 (dla.py:257-306; batch independent): logit_r = ELU(W[r] + b),
 // its log-softmax, and the inverse propensity weight pw_r = p_0 / p_r (dla.py:352-364).
 struct DlaTower { float pre, logit, logp, pw; };
-__device__ __forceinline__ DlaTower dla_tower(const float* __restrict__ prop_params, int L, int r, int prob_kind,
-                                              float max_pw) {
+// w_r, b: prop_params[r] (any value for r >= L) and prop_params[L], already in registers (a caller that requests them
+// early keeps the two loads off its critical path)
+__device__ __forceinline__ DlaTower dla_tower_regs(float w_r, float b, int L, int r, int prob_kind, float max_pw) {
   DlaTower t;
   const bool in_list = r < L;
-  t.pre = in_list ? prop_params[r] + prop_params[L] : 0.f;
+  t.pre = in_list ? w_r + b : 0.f;
   t.logit = eluf_(t.pre);
   const float tm = group_max<16>(in_list ? t.logit : -INFINITY);
   const float te = in_list ? expf(t.logit - tm) : 0.f;
@@ -111,6 +112,10 @@ __device__ __forceinline__ DlaTower dla_tower(const float* __restrict__ prop_par
   const float tprob0 = group_sum<16>(r == 0 ? tprob : 0.f);
   t.pw = in_list ? clip_w(tprob0 / tprob, max_pw) : 0.f;
   return t;
+}
+__device__ __forceinline__ DlaTower dla_tower(const float* __restrict__ prop_params, int L, int r, int prob_kind,
+                                              float max_pw) {
+  return dla_tower_regs(r < L ? prop_params[r] : 0.f, prop_params[L], L, r, prob_kind, max_pw);
 }
 
 // One (list, rank) lane of the rank loss (base_algorithm.py:228-251 / :163-186): the list's softmax pieces and
