@@ -21,6 +21,9 @@
 
 namespace ultr {
 
+#ifndef ULTR_TC_STAMP_LAYER
+#define ULTR_TC_STAMP_LAYER 2
+#endif
 constexpr int kTcThreads = 512, kTcRows = 16, kTcExch = 7 * 1024;
 constexpr int kTcMiscFloats = (ULTR_MAX_LAYERS + 1) * 32 + 32;  // row statistics [layer][16][2], scores [16], pad
 
@@ -83,11 +86,21 @@ struct TcRing { TcFrag s[kTcStages]; };
 
 // Geometry of one 16-row GEMM  out[16][N] = A[16][K] . Wm[K][ld]  over the 8 waves of the workgroup: a wave owns units
 // of 64 output columns; fewer than 8 units split the contraction over the idle waves (KS slices, meeting in LDS).
+typedef unsigned int tc_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kTcBufFlags = 0x00020000;  // raw buffer, 32-bit data format (word 3 of a gfx9 buffer descriptor)
 struct TcGeo {
   const float* W; int K, N, ld, U, Up, KS, ks, u_first, c_begin, c_last, nch;
+  // The weight stream goes through buffer loads: descriptor in scalar registers, ONE 32-bit vector add per chunk for
+  // the address (a flat load wants a 64-bit vector address per row: measured, the fp32 MFMA runs on the vector ALU, so
+  // every vector instruction in the loop comes straight out of the multiply time), and the descriptor's size ends at
+  // the wave's last chunk (or at row K): rows beyond the matrix and the loop's run-ahead loads past the end of the
+  // stream are out of range -- they return zeros and move nothing.
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned chunk_bytes, row_bytes;
   int dbg;  // diagnostic builds (-DULTR_STAMPS): 1 no weight loads
 };
-__device__ __forceinline__ TcGeo tc_geo(const float* W, int K, int N, int ld, int w) {
+// bf: the matrix is the packed bf16 copy (below)
+__device__ __forceinline__ TcGeo tc_geo(const float* W, int K, int N, int ld, int w, bool bf) {
   TcGeo g;
   g.W = W; g.K = K; g.N = N; g.ld = ld; g.dbg = 0;
   g.U = (N + 63) >> 6;
@@ -102,16 +115,17 @@ __device__ __forceinline__ TcGeo tc_geo(const float* W, int K, int N, int ld, in
   const int c_end = min(g.c_begin + cps, nchunks);
   g.nch = max(c_end - g.c_begin, 0);
   g.c_last = max(c_end - 1, 0);
+  // fp32: rows of ld floats; packed bf16: quad-rows of ld * 4 values of 2 bytes, zero rows up to a multiple of 16
+  g.row_bytes = (unsigned)ld * 4u;
+  g.chunk_bytes = bf ? 32u * (unsigned)ld : 64u * (unsigned)ld;
+  const unsigned bytes = bf ? (unsigned)c_end * g.chunk_bytes : (unsigned)min(16 * c_end, K) * g.row_bytes;
+  g.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)bytes, kTcBufFlags);
   return g;
 }
 // Chunk i of the wave's weight stream: rows 16 c + 4 kk + s (s = 0..3) of Wm, four consecutive columns from colc.
-// Full chunks: a wave-uniform row pointer (scalar registers) plus ONE per-lane 32-bit offset for all four loads.
-// FAST: the contraction length may stop short of the last chunk's 16 rows (layer 0 only: hidden widths are multiples
-// of 16); those rows are read all the same -- they lie inside the parameter buffer (checked on the host), are finite,
-// and meet zeros in the panel -- so the loop carries no clamps and no tail path.
 // BF: the matrix is the packed bf16 copy -- element (k, n) at ((k / 4) * ld + n) * 4 + k % 4 (in bf16), rows padded with
 // zeros to a multiple of 16 -- so a lane's 4 x 4 block of chunk i (rows 16 c + 4 kk .. + 3, columns colc .. colc + 3) is
-// 32 contiguous bytes, half of what the fp32 stream moves, and the last chunk needs neither clamps nor over-reads.
+// 32 contiguous bytes, half of what the fp32 stream moves.
 typedef short tc_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ tc_s16x4 tc_bf16x4(float a, float b, float c, float d) {
   const uint2 u = make_uint2(pk_bf16(a, b), pk_bf16(c, d));
@@ -121,48 +135,32 @@ __device__ __forceinline__ tc_s16x4 tc_as_bf16x4(float lo, float hi) {
   const float2 u = make_float2(lo, hi);
   return __builtin_bit_cast(tc_s16x4, u);
 }
+// voff: the lane's byte offset inside a chunk (tc_voff).  Loads are UNCONDITIONAL: a branch around them would leave the
+// number of loads in flight unknown at the loop header, and the compiler would then drain every outstanding load there
+// (s_waitcnt vmcnt(0)) instead of waiting for the oldest chunk only; past the end of the stream they are out of range.
 template <bool FAST, bool BF>
-__device__ __forceinline__ void tc_wload(const TcGeo& g, int colc, unsigned voff, int i, int kk, TcFrag& S) {
-  if (BF) {
-    const bool on = i < g.nch;  // wave-uniform; past the end every lane re-reads the head of the stream (see below)
-    const int c = on ? g.c_begin + i : 0;
-    const float* rowp = g.W + (size_t)(8 * c) * g.ld;  // 4 c quad-rows of ld * 8 bytes
-    const unsigned vo = on ? voff : 0u;
-    S.b[0] = *reinterpret_cast<const float4*>(rowp + vo);
-    S.b[1] = *reinterpret_cast<const float4*>(rowp + vo + 4);
-    return;
-  }
+__device__ __forceinline__ void tc_wload(const TcGeo& g, unsigned voff, int i, TcFrag& S) {
 #ifdef ULTR_STAMPS
-  if (g.dbg & 1) {
+  if (!BF && (g.dbg & 1)) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) S.b[s] = make_float4(0.f, 1.f, 2.f, 3.f);
     return;
   }
+  if (g.dbg & 2) i = 0;  // every chunk re-reads the wave's first one: L1 hits, no L2 traffic (timing only)
 #endif
-  // Loads are UNCONDITIONAL: a branch around them would leave the number of loads in flight unknown at the loop
-  // header, and the compiler would then drain every outstanding load there (s_waitcnt vmcnt(0)) instead of waiting
-  // for the oldest chunk only.  Past the end of the stream (i >= nch) all lanes read the first 16 bytes of a row of
-  // the matrix's first chunk: one cache line per load, nothing new from L2.
-  const bool on = i < g.nch;  // wave-uniform
-  int c = on ? g.c_begin + i : 0;
-#ifdef ULTR_STAMPS
-  if (g.dbg & 2) c = g.c_begin;  // every chunk re-reads the wave's first one: L1 hits, no L2 traffic (timing only)
-#endif
-  if (FAST || 16 * c + 16 <= g.K) {
-    const float* rowp = g.W + (size_t)(16 * c) * g.ld;
-    const unsigned vo = on ? voff : 0u;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) S.b[s] = *reinterpret_cast<const float4*>(rowp + (size_t)(s * g.ld) + vo);
-  } else {  // the last, partial chunk: rows clamped into the matrix (the panel holds zeros there)
-    const int k0 = 16 * c + 4 * kk;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      S.b[s] = *reinterpret_cast<const float4*>(g.W + (size_t)min(k0 + s, g.K - 1) * g.ld + colc);
+  const unsigned vo = voff + (unsigned)(g.c_begin + i) * g.chunk_bytes;
+  if (BF) {
+    S.b[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, vo, 0, 0));
+    S.b[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, vo, 16, 0));
+    return;
   }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    S.b[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, vo, (int)(s * g.row_bytes), 0));
 }
-// per-lane offset (in floats) of the lane's block inside a chunk
+// per-lane byte offset of the lane's block inside a chunk
 template <bool BF> __device__ __forceinline__ unsigned tc_voff(const TcGeo& g, int colc, int kk) {
-  return BF ? (unsigned)(2 * (kk * g.ld + colc)) : (unsigned)(4 * kk * g.ld + colc);
+  return 4u * (BF ? (unsigned)(2 * (kk * g.ld + colc)) : (unsigned)(4 * kk * g.ld + colc));
 }
 // ALWAYS: waves without a unit of their own request (clamped, in-bounds) chunks as well, so that the number of loads
 // this call puts in flight is the same on every path and a later wait for OLDER loads can be a counted one
@@ -172,7 +170,7 @@ __device__ __forceinline__ void tc_prefetch(const TcGeo& g, int nn, int kk, TcRi
     const int colc = min(64 * g.u_first + 4 * nn, g.ld - 4);
     const unsigned voff = tc_voff<BF>(g, colc, kk);
 #pragma unroll
-    for (int i = 0; i < kTcStages - 1; ++i) tc_wload<FAST, BF>(g, colc, voff, i, kk, R.s[i]);
+    for (int i = 0; i < kTcStages - 1; ++i) tc_wload<FAST, BF>(g, voff, i, R.s[i]);
   }
 }
 
@@ -237,7 +235,7 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
     const unsigned voff = tc_voff<BF>(g, colc, kk);
     if (u != g.u_first) {
 #pragma unroll
-      for (int i = 0; i < kTcStages - 1; ++i) tc_wload<FAST, BF>(g, colc, voff, i, kk, R.s[i]);
+      for (int i = 0; i < kTcStages - 1; ++i) tc_wload<FAST, BF>(g, voff, i, R.s[i]);
     }
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) b4 = *reinterpret_cast<const float4*>(bias + min(64 * u + 4 * nn, ((g.N + 3) & ~3) - 4));
@@ -272,7 +270,7 @@ __device__ __forceinline__ void tc_gemm(const TcGeo& g, float* A, int PS, int nn
       }
       a_cur = a_nxt;
     };
-#define TC_LOAD(i, S) tc_wload<FAST, BF>(g, colc, voff, (i), kk, S)
+#define TC_LOAD(i, S) tc_wload<FAST, BF>(g, voff, (i), S)
 #define TC_COMPUTE(S, i) compute(S, (i))
     TC_STREAM(g.nch, TC_LOAD, TC_COMPUTE);
 #undef TC_LOAD
@@ -445,7 +443,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
       }
     }
   }
-  TcGeo g = tc_geo(BF ? p.Wp[0] : p.W[0], p.K[0], p.N[0], p.ldn[0], w);
+  TcGeo g = tc_geo(BF ? p.Wp[0] : p.W[0], p.K[0], p.N[0], p.ldn[0], w, BF);
   g.dbg = p.dbg;
 
   // ---- input stage of layer 0: gathered rows, normalised with the table's statistics
@@ -510,6 +508,9 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
         warm[r] = *src;
       }
     }
+    // the loss constants' arithmetic, while the gathered rows are on their way (its operands came with the doc ids)
+    if (RIDE == ULTR_RIDE_DLA) wgt_l = dla_tower_regs(tower_w, tower_b, L, r_l, p.dla.prob_kind, p.dla.max_pw).pw;
+    if (RIDE == ULTR_RIDE_IPW && p.ipw.ipw_table) wgt_l = live && c_l > 0.f ? ipw_t : 0.f;  // ipw_weight()
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
       const int row = w + 8 * r2;
@@ -541,10 +542,6 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   for (int j = 0; j < H; ++j) {
     const int N = p.N[j];
     lds_barrier();  // the input panel is complete
-    if (j == 0) {   // the loss constants' arithmetic, off the gather's critical path
-      if (RIDE == ULTR_RIDE_DLA) wgt_l = dla_tower_regs(tower_w, tower_b, L, r_l, p.dla.prob_kind, p.dla.max_pw).pw;
-      if (RIDE == ULTR_RIDE_IPW && p.ipw.ipw_table) wgt_l = live && c_l > 0.f ? ipw_t : 0.f;  // ipw_weight()
-    }
     // gamma / beta of the NEXT input stage and this layer's bias ride along with the weight stream
     {
       const int K = p.K[j + 1], nq = (((K + 15) & ~15) + 255) >> 8, k_last4 = ((K + 3) & ~3) - 4;
@@ -580,11 +577,11 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
           *reinterpret_cast<float4*>(actj + (4 * kk + r) * aps + col0) = v;
         }
       }
-    }, j == 2 ? 10 : -1);
+    }, j == ULTR_TC_STAMP_LAYER ? 10 : -1);
     TC_STAMP(2 + 3 * j);
     TC_WSTAMP(3 * j + 1);
     if (j + 1 < H) {  // the next layer's weight stream starts before its rows are normalised
-      g = tc_geo(BF ? p.Wp[j + 1] : p.W[j + 1], p.K[j + 1], p.N[j + 1], p.ldn[j + 1], w);
+      g = tc_geo(BF ? p.Wp[j + 1] : p.W[j + 1], p.K[j + 1], p.N[j + 1], p.ldn[j + 1], w, BF);
       g.dbg = p.dbg;
       tc_prefetch<FAST, BF>(g, nn, kk, R);
     }
@@ -884,7 +881,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   // the transposed weights of the first dgrad GEMM stream in under the partial-row reduction
   int cur_is_p1 = 1;
   if (H >= 2) {
-    g = tc_geo(BF ? p.WTp[H - 1] : p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w);
+    g = tc_geo(BF ? p.WTp[H - 1] : p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w, BF);
     g.dbg = p.dbg;
     tc_prefetch<FAST, BF>(g, nn, kk, R);
   }
@@ -929,7 +926,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
       }
     });
     if (j >= 2) {  // the next layer's weight stream starts under the row pass
-      g = tc_geo(BF ? p.WTp[j - 1] : p.WT[j - 1], p.N[j - 1], p.K[j - 1], (p.K[j - 1] + 3) & ~3, w);
+      g = tc_geo(BF ? p.WTp[j - 1] : p.WT[j - 1], p.N[j - 1], p.K[j - 1], (p.K[j - 1] + 3) & ~3, w, BF);
       g.dbg = p.dbg;
       tc_prefetch<FAST, BF>(g, nn, kk, R);
     }
