@@ -265,13 +265,18 @@ int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const 
  *   `scores` must be this call's `scores` and its B, L this call's (ULTR_EINVAL otherwise; the request is consumed).
  *   The chain kernel evaluates d_score with the loss kernels' own lane functions (same bits) and writes scores and the
  *   list weights; the request's statistics (and d_scores, prop_grads, pw_out) are produced by rider workgroups of the
- *   weight-gradient launch.  A parked ultr_metrics_deferred request rides there too, a parked
- *   ultr_batch_assemble_deferred request with the last launch.
+ *   slab-reduction launch (the third of the step's launches).  A parked ultr_metrics_deferred request rides there too
+ *   (lists of 9 to 16, at most 1024 lists; otherwise it gets a launch of its own), a parked
+ *   ultr_batch_assemble_deferred request with the update launch (ultr_clip_adagrad_fused).
+ *   Two row tiles: 16 rows per workgroup while the batch is at most one workgroup per CU (256 workgroups), 32 rows
+ *   (chain32.hpp: the reference's default scorer -- elu, layer normalisation, hidden widths multiples of 16 -- in
+ *   fp32, widths up to 768) beyond; ultr_dnn_fused_rows says which one a (desc, B, L) gets (0: not supported).
  *   grads[0..n_params) and sumsq (may be NULL) as ultr_dnn_backward_sumsq.  docids [L][B] position-major.
  * ultr_dnn_fused_workspace_bytes: bytes of workspace for (B, L); 0 when the shape is not supported (no hidden layer,
  * L > 16, widths whose 16-row panels do not fit the 160 KB of LDS) -- use the separate entry points then; -1 on a bad
  * descriptor. */
 long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int B, int L);
+int ultr_dnn_fused_rows(const UltrDnnDesc* desc, int B, int L);
 /* workspace: zero-initialised by the caller before its first use and used for this (desc, B, L) only.
  * wt_fresh != 0: the transposed weight copies the workspace keeps for the dgrad GEMMs are current, i.e. the
  *   parameters have not changed since the last ultr_clip_adagrad_fused call on this workspace; 0: they are rebuilt

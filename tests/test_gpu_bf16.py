@@ -103,8 +103,9 @@ def test_bf16_weight_copies_follow_the_parameters():
 
 
 def test_bf16_step_stays_fused_beyond_the_fp32_row_limit():
-    """The fp32 fused step hands over to the per-launch plan above 12288 rows; the bf16 step does not (it is faster at
-    every size).  1536 lists of 10: still the fused path, still inside the stated bound."""
+    """The 16-row fp32 fused step hands over above 12288 rows; the bf16 step does not (it is faster at every size), and
+    neither does the default scorer in fp32, which runs the 32-row kernel there.  1536 lists of 10: both fused, the
+    bf16 one still inside the stated bound."""
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
     B, L, F = 1536, 10, 136
     data = SyntheticData(2000, L, F, seed=9, pad_frac=0.1)
@@ -118,7 +119,7 @@ def test_bf16_step_stays_fused_beyond_the_fp32_row_limit():
         out[dt] = (m._train_bufs['fused'], m._train_bufs['scores'].cpu().numpy(),
                    (m._train_bufs['grads'] / m._train_bufs['stats'][1]).cpu().numpy())
         m.step_apply()
-    assert out['bf16'][0] and not out['f32'][0]
+    assert out['bf16'][0] and out['f32'][0] and m.model.fused_rows(B, L) == 16  # (m: the bf16 model, 16-row kernel)
     assert relerr(out['bf16'][1], out['f32'][1]) < 1e-2
     assert relerr(out['bf16'][2], out['f32'][2]) < 2e-2
 

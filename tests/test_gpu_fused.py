@@ -37,19 +37,27 @@ CASES = [
     ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 10, 1),
     ('RegressionEM', '', 'hidden_layer_sizes=[8]', 5, 6, 20),
     ('DLA', '', 'hidden_layer_sizes=[768, 16]', 40, 10, 24),
+    # more than 256 workgroups of the 16-row kernel: the 32-row kernel (chain32.hpp) -- three lists of 10 per workgroup
+    # at the three data-set widths, four lists of 8, two lists of 16, a last workgroup with one list of its three
+    ('DLA', '', 'hidden_layer_sizes=[512, 256, 128]', 136, 10, 700),
+    ('RegressionEM', '', 'hidden_layer_sizes=[512, 256, 128]', 700, 10, 260),
+    ('PairDebias', '', 'hidden_layer_sizes=[512, 256, 128]', 220, 10, 301),
+    ('IPWrank', 'propensity_estimator_json=%s' % IPW_JSON, 'hidden_layer_sizes=[128, 64]', 40, 8, 520),
+    ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 16, 258),
 ]
 
 
 @pytest.mark.parametrize('algo,hp,mhp,F,L,B', CASES)
 def test_fused_step_equals_the_per_launch_plan(algo, hp, mhp, F, L, B):
     from ultra_amd.learning_algorithm.base_algorithm import DEVICE_BATCH_KEY
-    data = SyntheticData(300, L, F, seed=11, pad_frac=0.2 if L > 2 else 0.0)
+    data = SyntheticData(max(300, B), L, F, seed=11, pad_frac=0.2 if L > 2 else 0.0)
     click = CASCADE if algo == 'PairDebias' else PBM
     exp = settings(algo, hp, mhp, Lmax=L, cutoff=L, feed_hparams='click_model_json=%s' % click)
     m1, feed = make(algo, data, exp, B)
     m2, _ = make(algo, data, exp, B)
     m2.fused_step = False
     assert m1.model.fused_supported(B, L)
+    assert m1.model.fused_rows(B, L) == (32 if B > 256 else 16)
     rng = np.random.RandomState(2)
     for step in range(3):
         feed_dict, _ = feed.get_batch(data, check_validation=True)

@@ -253,6 +253,20 @@ __device__ __forceinline__ void ld_kstrided(const float* __restrict__ W, int ld,
 #pragma unroll
   for (int t = 0; t < 16; ++t) f[t] = W[base + (unsigned)t * (unsigned)ld];
 }
+// The same stream through buffer loads: descriptor and row offsets in scalar registers, ONE vector add per chunk.  The
+// fp32 MFMA runs on the vector ALU, so the sixteen 64-bit address computations a chunk of flat loads costs came straight
+// out of the multiply time (measured: 108 vector instructions per 32 MFMAs in the large-batch forward kernel).  The
+// descriptor ends at row K: rows beyond the matrix read as zero, so the tail chunk needs no clamps.
+constexpr int kRawBufFlags = 0x00020000;  // raw buffer, 32-bit data format (word 3 of a gfx9 buffer descriptor)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* W, int K, int ld) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)((unsigned)K * (unsigned)ld * 4u), kRawBufFlags);
+}
+__device__ __forceinline__ void ld_kstrided_buf(__amdgpu_buffer_rsrc_t rs, int ld, int kk0, unsigned lane_off, float (&f)[16]) {
+  const unsigned vo = 4u * ((unsigned)kk0 * (unsigned)ld + lane_off);
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    f[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (int)(4u * (unsigned)t * (unsigned)ld), 0));
+}
 // tail chunk (kk0 + 32 > K): row indices clamped to the last valid row (the panel holds zeros there)
 __device__ __forceinline__ void ld_kstrided_tail(const float* __restrict__ W, int ld, int kk0, int h, int colc, int k_last,
                                                  float (&f)[16]) {
@@ -339,7 +353,7 @@ __global__ void __launch_bounds__(64 * WN * WK, RT == 1 ? 2 : 1) fwd_layer_kerne
   const bool col_ok = col < p.N;
   const int colc = min(col, p.ldn - 1);
   const unsigned lane_off = (unsigned)(16 * h * p.ldn + colc);
-  const int k_last = p.K - 1;
+  const __amdgpu_buffer_rsrc_t w_rs = weight_rsrc(p.W, p.K, p.ldn);
   struct Frag { float b[16]; } S0, S1, S2;
   f32x16 acc[RT];
 #pragma unroll
@@ -359,8 +373,7 @@ __global__ void __launch_bounds__(64 * WN * WK, RT == 1 ? 2 : 1) fwd_layer_kerne
 #define FWD_LOAD(i, S)                                                                        \
   do {                                                                                       \
     const int kk0_ = kp0 + 32 * min(c_begin + (i), c_last);                                  \
-    if (kk0_ + 32 <= p.K) ld_kstrided(p.W, p.ldn, kk0_, lane_off, S.b);                      \
-    else ld_kstrided_tail(p.W, p.ldn, kk0_, h, colc, k_last, S.b);                           \
+    ld_kstrided_buf(w_rs, p.ldn, kk0_, lane_off, S.b);                                       \
   } while (0)
     FWD_LOAD(0, S0);  // the weight stream starts before the panel is staged
     FWD_LOAD(1, S1);

@@ -64,6 +64,7 @@ struct TcArgs {
   float* list_weights;                            // [B] or NULL
   float* outpart;                                 // [gridDim.x][3 K_H + 4] output-layer gradient partials
   int PS;                                         // row stride of the two LDS panels (== 4 mod 32)
+  int PS2;                                        // 32-row kernel: row stride of the second panel (hidden widths only)
   int panel_floats;                               // floats per panel
   int act_off[ULTR_MAX_LAYERS], act_ps[ULTR_MAX_LAYERS];  // LDS: activations of hidden layer j, [16][act_ps]
   int p1_off, p2_off, misc_off;
@@ -1019,6 +1020,10 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   if (warm[0] + warm[1] == 1.2345e-30f && p.B < 0) p.outpart[0] = warm[0];  // never true: keeps the warm-up loads alive
 }
 
+}  // namespace ultr
+#include "chain32.hpp"
+namespace ultr {
+
 // WT_j[n][k] = W_j[k][n] for the hidden layers j >= 1 (32 x 32 tiles through LDS), one launch for all of them: the
 // step's preparation launch when the caller's update call has not refreshed the copies (ultr_clip_adagrad_fused does).
 struct TransposeArgs {
@@ -1238,6 +1243,9 @@ __global__ void __launch_bounds__(kThreads) finalize_fused_kernel(FinalizeFusedA
 // ---------------------------------------------------------------------------------------------
 struct FusedPlan {
   int H, nl, nwg;
+  int rows;  // 16: train_chain_kernel; 32: train_chain32_kernel (batches of more than one workgroup per CU)
+  int PS2;
+  bool fast;  // the reference's default scorer with aligned widths: the compile-time specialised kernels
   int K[ULTR_MAX_LAYERS], N[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS];
   int PS, panel_floats, act_off[ULTR_MAX_LAYERS], act_ps[ULTR_MAX_LAYERS], p1_off, p2_off, misc_off;
   size_t smem_bytes;
@@ -1250,6 +1258,12 @@ struct FusedPlan {
   bool ok;
 };
 
+// The 32-row kernel pays while the 16-row one would need more than one workgroup per CU (256 CUs): ULTR_FUSED_ROWS=16|32
+// forces one of them (diagnostics, tests).
+static int fused_rows_override() {
+  static const int v = [] { const char* e = getenv("ULTR_FUSED_ROWS"); return e ? atoi(e) : 0; }();
+  return v;
+}
 static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   FusedPlan P{};
   P.ok = false;
@@ -1257,19 +1271,43 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   P.bf16 = d->compute_dtype == ULTR_DTYPE_BF16;
   if (P.H < 1 || L < 1 || L > 16 || B < 1) return P;
   if (d->norm != ULTR_NORM_NONE && d->norm != ULTR_NORM_LAYER) return P;  // batch statistics couple the rows: per-layer plan
-  P.nl = 16 / L;
-  if (P.nl > 4) P.nl = 4;  // one 16-lane group per list in the loss lanes of a wave
-  P.nwg = (int)cdiv(B, P.nl);
   const long long M = (long long)B * L;
-  int cur = d->in_features, maxw = d->in_features;
+  int cur = d->in_features, maxw = d->in_features, maxh = 0;
   for (int j = 0; j <= P.H; ++j) {
     P.K[j] = cur;
     P.N[j] = d->sizes[j];
     P.ldn[j] = round4(d->sizes[j]);
     cur = d->sizes[j];
     if (j < P.H && P.N[j] > maxw) maxw = P.N[j];
+    if (j < P.H && P.N[j] > maxh) maxh = P.N[j];
   }
   if (maxw > 1024) return P;
+  P.fast = d->activation == ULTR_ACT_ELU && d->norm == ULTR_NORM_LAYER && (P.K[0] & 3) == 0;
+  for (int j = 1; j <= P.H; ++j) P.fast = P.fast && (P.K[j] & 15) == 0;
+  const int nl16 = 16 / L > 4 ? 4 : 16 / L;  // one 16-lane group per list in the loss lanes of a wave
+  // ---- 32 rows per workgroup?
+  P.rows = 16;
+  {
+    const int nl32 = 32 / L > 4 ? 4 : 32 / L;
+    const int PSa = ((maxw + 31) & ~31) + 4, PSb = ((maxh + 31) & ~31) + 4;
+    // (either panel serves as the split-K exchange buffer of the GEMM that has just multiplied it out)
+    const int pa = kC32Rows * PSa > 7 * 2048 ? kC32Rows * PSa : 7 * 2048, pb = kC32Rows * PSb > 7 * 2048 ? kC32Rows * PSb : 7 * 2048;
+    const size_t bytes = sizeof(float) * ((size_t)pa + pb + kC32MiscFloats);
+    const bool can32 = P.fast && !P.bf16 && maxw <= 768 && nl32 > nl16 && bytes <= 160 * 1024 && 8 * (3 * P.K[P.H] + 1) <= pb;
+    const int ov = fused_rows_override();
+    if (can32 && (ov == 32 || (ov != 16 && cdiv(B, nl16) > 256))) {
+      P.rows = 32;
+      P.nl = nl32;
+      P.nwg = (int)cdiv(B, P.nl);
+      P.PS = PSa; P.PS2 = PSb;
+      P.panel_floats = pa;
+      P.p1_off = 0; P.p2_off = pa; P.misc_off = pa + pb;
+      P.smem_bytes = bytes;
+    }
+  }
+  if (P.rows == 16) {
+  P.nl = nl16;
+  P.nwg = (int)cdiv(B, P.nl);
   P.PS = ((maxw + 31) & ~31) + 4;
   P.panel_floats = kTcRows * P.PS > kTcExch ? kTcRows * P.PS : kTcExch;
   if (8 * (3 * P.K[P.H] + 1) > P.panel_floats) return P;
@@ -1284,6 +1322,7 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   P.misc_off = off; off += kTcMiscFloats;
   P.smem_bytes = sizeof(float) * (size_t)off;
   if (P.smem_bytes > 160 * 1024) return P;
+  }
   long long o = 0;
   auto take = [&](long long n) {
     const long long at = o;
@@ -1363,6 +1402,12 @@ extern "C" int ultr_debug_tc_stamps(long long* host, int n) {
 }
 #endif
 
+extern "C" int ultr_dnn_fused_rows(const UltrDnnDesc* desc, int B, int L) {
+  if (ultr_check_desc(desc, "ultr_dnn_fused_rows") != ULTR_OK) return -1;
+  const FusedPlan P = make_fused_plan(desc, B, L);
+  return P.ok ? P.rows : 0;
+}
+
 extern "C" long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int B, int L) {
   if (ultr_check_desc(desc, "ultr_dnn_fused_workspace_bytes") != ULTR_OK) return -1;
   const FusedPlan P = make_fused_plan(desc, B, L);
@@ -1382,6 +1427,26 @@ static int launch_chain3(const TcArgs& a, int nwg, size_t smem, hipStream_t st) 
     hipLaunchKernelGGL((train_chain_kernel<RIDE, FAST, NQ, BF>), dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
   }
   return check_launch("train_chain_kernel");
+}
+template <int RIDE, int NQ>
+static int launch_chain32(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
+  static PerDeviceOnce attr_done;
+  if (const int rc_ = raise_lds_limit(attr_done, reinterpret_cast<const void*>(train_chain32_kernel<RIDE, NQ>), 160 * 1024,
+                                      "ultr_dnn_train_fused")) return rc_;
+  long long pw = 0;
+  for (int j = 0; j < a.H; ++j) pw += (long long)a.K[j] * a.N[j] + (j >= 1 ? (long long)a.K[j] * a.N[j] : 0);
+  {
+    ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("train_chain32_kernel/P%lld", pw) : "train_chain32_kernel", st);
+    hipLaunchKernelGGL((train_chain32_kernel<RIDE, NQ>), dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
+  }
+  return check_launch("train_chain32_kernel");
+}
+template <int RIDE>
+static int launch_chain32_q(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
+  int maxk = 0;
+  for (int j = 0; j <= a.H; ++j) maxk = a.K[j] > maxk ? a.K[j] : maxk;
+  if (maxk <= 512) return launch_chain32<RIDE, 2>(a, nwg, smem, st);
+  return launch_chain32<RIDE, 3>(a, nwg, smem, st);
 }
 template <int RIDE, bool FAST, int NQ>
 static int launch_chain2(const TcArgs& a, int nwg, size_t smem, hipStream_t st) {
@@ -1488,17 +1553,20 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   }
   a.scores = scores;
   a.outpart = ws + P.outpart;
-  a.PS = P.PS; a.panel_floats = P.panel_floats; a.p1_off = P.p1_off; a.p2_off = P.p2_off; a.misc_off = P.misc_off;
+  a.PS = P.PS; a.PS2 = P.PS2; a.panel_floats = P.panel_floats; a.p1_off = P.p1_off; a.p2_off = P.p2_off; a.misc_off = P.misc_off;
 #ifdef ULTR_STAMPS
   { const char* e = getenv("ULTR_TC_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
   a.dla = pl.dla; a.ipw = pl.ipw; a.rem = pl.rem; a.pd = pl.pd;
   a.list_weights = pl.kind == ULTR_RIDE_DLA ? pl.dla.list_weights : pl.kind == ULTR_RIDE_IPW ? pl.ipw.list_weights
                    : pl.kind == ULTR_RIDE_REM ? pl.rem.list_weights : nullptr;
-  bool fast = desc->activation == ULTR_ACT_ELU && has_ln && (P.K[0] & 3) == 0;
-  for (int j = 1; j <= H; ++j) fast = fast && (P.K[j] & 15) == 0;
-  if (!P.bf16) fast = fast && desc->off_W[0] + (long long)((P.K[0] + 15) & ~15) * P.ldn[0] <= desc->n_params;
-  if (pl.kind == ULTR_RIDE_DLA) rc = launch_chain<ULTR_RIDE_DLA>(a, P.nwg, P.smem_bytes, fast, st);
+  const bool fast = P.fast;
+  if (P.rows == 32) {
+    if (pl.kind == ULTR_RIDE_DLA) rc = launch_chain32_q<ULTR_RIDE_DLA>(a, P.nwg, P.smem_bytes, st);
+    else if (pl.kind == ULTR_RIDE_IPW) rc = launch_chain32_q<ULTR_RIDE_IPW>(a, P.nwg, P.smem_bytes, st);
+    else if (pl.kind == ULTR_RIDE_REM) rc = launch_chain32_q<ULTR_RIDE_REM>(a, P.nwg, P.smem_bytes, st);
+    else rc = launch_chain32_q<ULTR_RIDE_PD>(a, P.nwg, P.smem_bytes, st);
+  } else if (pl.kind == ULTR_RIDE_DLA) rc = launch_chain<ULTR_RIDE_DLA>(a, P.nwg, P.smem_bytes, fast, st);
   else if (pl.kind == ULTR_RIDE_IPW) rc = launch_chain<ULTR_RIDE_IPW>(a, P.nwg, P.smem_bytes, fast, st);
   else if (pl.kind == ULTR_RIDE_REM) rc = launch_chain<ULTR_RIDE_REM>(a, P.nwg, P.smem_bytes, fast, st);
   else rc = launch_chain<ULTR_RIDE_PD>(a, P.nwg, P.smem_bytes, fast, st);

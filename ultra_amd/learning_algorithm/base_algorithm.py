@@ -388,10 +388,12 @@ class BaseAlgorithm(ABC):
     # ULTR_FUSED_STEP=0: forward, loss and backward pass as separate calls even for short lists
     fused_step = os.environ.get('ULTR_FUSED_STEP', '1') != '0'
 
-    # The fused step's workgroups own whole lists and each streams every weight: it wins while the batch fits the chip
-    # a few times over (measured against the per-launch plan: 90 against 131 us at 2560 rows, 279 against 297 at 10240,
-    # 414 against 405 at 15360, 1094 against 808 at 40960); beyond that the per-layer kernels, which share weight
-    # tiles between workgroups, are the better plan.  ULTR_FUSED_MAX_ROWS overrides the threshold.
+    # The 16-row fused step's workgroups own one MFMA tile of whole lists and each streams every weight: it wins while
+    # the batch fits the chip a few times over (measured against the per-launch plan: 90 against 131 us at 2560 rows,
+    # 279 against 297 at 10240, 414 against 405 at 15360, 1094 against 808 at 40960); beyond that the per-layer kernels,
+    # which share weight tiles between workgroups, are the better plan.  ULTR_FUSED_MAX_ROWS overrides the threshold.
+    # Shapes the 32-row fused step takes (the default scorer in fp32: DNN.fused_rows) stay fused at every size: 713 us
+    # against 802 us for the per-launch plan at 40960 rows, 224 against 302 us for the 16-row step at 10240.
     fused_max_rows = int(os.environ.get('ULTR_FUSED_MAX_ROWS', '12288'))
 
     def _fused_ok(self, batch):
@@ -399,8 +401,9 @@ class BaseAlgorithm(ABC):
         # (the bf16 step streams half the bytes and spends next to nothing on MFMA: it stays ahead of the fp32 per-launch
         # plan at every size -- 613 against 810 us at 40960 rows -- so only the fp32 step hands over)
         bf16 = self.model.desc.compute_dtype == _lib.DTYPE_BF16
-        return self.fused_step and self._loss_rides() and (bf16 or batch.B * batch.L <= self.fused_max_rows) and \
-            self.model.fused_supported(batch.B, batch.L)
+        if not (self.fused_step and self._loss_rides() and self.model.fused_supported(batch.B, batch.L)):
+            return False
+        return bf16 or batch.B * batch.L <= self.fused_max_rows or self.model.fused_rows(batch.B, batch.L) == 32
 
     def _step_local_fused(self, tb, batch):
         scores = tb['scores']

@@ -211,6 +211,10 @@ class DNN(BaseRankingModel):
         """True when (B lists of L) can run as the fused training step (``ultr_dnn_train_fused``)."""
         return self._fused_workspace(B, L) is not None
 
+    def fused_rows(self, B, L):
+        """Rows per workgroup of the fused step for (B, L): 16, 32 (large batches, chain32.hpp) or 0 (not supported)."""
+        return int(_lib.lib().ultr_dnn_fused_rows(self.desc, int(B), int(L)))
+
     def _fused_workspace(self, B, L):
         key = ('fused', B, L)
         if key not in self._ws:
