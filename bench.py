@@ -208,8 +208,8 @@ def main():
                          '(before / after the collective) with the RCCL all-reduce issued between them.  Default: 1 on '
                          'one GPU, 2 on several')
     ap.add_argument('--graph_steps', type=int, default=0,
-                    help='--graph 1 only: consecutive steps captured into one hipGraph (--steps must be a multiple); '
-                         '0 = the largest of 8 .. 1 that divides --steps')
+                    help='--graph 1 only: consecutive steps captured into one hipGraph (0 = four, whatever --steps is; '
+                         'steps beyond a multiple are launched eagerly)')
     ap.add_argument('--force_collective', action='store_true',
                     help='single-GPU rehearsal of the multi-GPU launch path: a 1-rank RCCL group, all-reduce issued anyway')
     ap.add_argument('--algo_hparams', default='')
@@ -250,16 +250,18 @@ def main():
         cfg[k] = type(cfg[k])(v)
     with contextlib.redirect_stdout(sys.stderr):  # the plugin classes print progress lines like the reference does
         data, exp, model, feed = build_world(cfg, args, device)
-    use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 2)
+    dp = world > 1 or args.force_collective
+    if args.force_collective:
+        model.force_dp_plan = True  # the launch plan of several ranks (norm inside the update launch, reduced metric rows)
+    use_graph = args.graph if args.graph >= 0 else 1
+    # Steps per captured graph: FOUR whatever --steps is (so that a 20-step and a 200-step run are the same experiment);
+    # steps beyond a multiple of four are launched eagerly.  --graph_steps overrides.
     if args.graph_steps <= 0:
-        args.graph_steps = next(k for k in range(8, 0, -1) if args.steps % k == 0)
-    if use_graph == 1 and (world > 1 or args.force_collective):
-        use_graph = 2  # the collective is never captured
+        args.graph_steps = 4
 
     def collective():
         if args.force_collective and world == 1:
-            tb = model._train_bufs
-            torch.distributed.all_reduce(tb['bucket'][:tb['n_reduce']])
+            torch.distributed.all_reduce(model._train_bufs['reduce'])
         else:
             model.step_reduce()
 
@@ -291,19 +293,34 @@ def main():
             model.enable_graph_replay(True)
             step()
             torch.cuda.synchronize()
+            captured = False
             if use_graph == 1:
                 # --graph_steps consecutive steps per graph: kernels inside a graph run back to back, while two replays
                 # are a few microseconds apart.  Every captured step publishes into its own pinned ring slot, so
-                # each step's loss and summary stay readable after a replay.
-                if args.graph_steps > 1:
-                    model.enable_graph_replay(False)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    for _ in range(args.graph_steps):
-                        last_of['hipGraph replay'] = step()
-                steps_per_call['hipGraph replay'] = args.graph_steps
-                paths['hipGraph replay'] = graph.replay
-            else:
+                # each step's loss and summary stay readable after a replay.  With several ranks the RCCL all-reduce
+                # is captured INSIDE the graph (torch's process group supports capture); if RCCL refuses, the split
+                # plan below takes over.
+                try:
+                    if args.graph_steps > 1:
+                        model.enable_graph_replay(False)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        for _ in range(args.graph_steps):
+                            last_of['hipGraph replay'] = step()
+                    name = 'hipGraph replay' + (' (RCCL all-reduce captured)' if dp else '')
+                    last_of[name] = last_of['hipGraph replay']
+                    steps_per_call[name] = args.graph_steps
+                    paths[name] = graph.replay
+                    captured = True
+                except Exception as e:  # noqa: BLE001
+                    if not dp:
+                        raise
+                    log('capturing the collective failed (%s: %s); two graphs around an eager all-reduce' % (type(e).__name__, e))
+                    torch.cuda.synchronize()
+                    model.enable_graph_replay(True)
+                    step()
+                    torch.cuda.synchronize()
+            if not captured:
                 # feed + forward + loss + metrics + backward | all-reduce (eager, RCCL's own stream) | update + publish
                 graph, graph_apply = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
@@ -345,12 +362,13 @@ def main():
     run = paths[launch]
 
     spc = steps_per_call.get(launch, 1)
-    if args.steps % spc:
-        raise SystemExit('--steps %d is not a multiple of --graph_steps %d' % (args.steps, spc))
+    rest = args.steps % spc                                # steps beyond a multiple of the graph's: eager launches
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps // spc):                     # exactly args.steps steps
         r = run()
+    for _ in range(rest):
+        r_rest = step()
     barrier()
     dt = time.perf_counter() - t0
     last = r if launch == 'eager' else last_of[launch]

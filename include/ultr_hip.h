@@ -21,31 +21,33 @@
  *           ultr_batch_assemble_deferred, ultr_rem_update_propensity_deferred,
  *           ultr_pd_update_ratios_deferred -- and ultr_dnn_train_fused itself, which parks the last
  *           step of a metric evaluation it carried for the next ultr_clip_adagrad* call, see
- *           ultr_metrics_tail_flush) PARK one request per kind PER HOST THREAD (thread_local):
- *           nothing is launched; a later carrying call made BY THE SAME THREAD (ultr_dnn_backward*,
+ *           ultr_metrics_tail_flush) PARK one request per kind in a REQUEST CONTEXT: nothing is
+ *           launched; a later carrying call made WITH THE SAME CONTEXT BOUND (ultr_dnn_backward*,
  *           ultr_dnn_train_fused, ultr_clip_adagrad_fused; each request's comment names its carriers)
  *           launches the parked work inside one of its own launches, on the CARRIER's stream.
- *           What follows from that:
+ *           The context is the one bound to the calling host thread: ultr_pending_create() makes
+ *           one, ultr_pending_bind(ctx) binds it to the calling thread (NULL = the thread's own
+ *           default context, which is what a caller that never binds gets).  One context per model,
+ *           bound before each group of calls made for that model, keeps models stepped alternately
+ *           on one thread -- phases interleaved, feeds prefetching -- entirely apart: a request is
+ *           only ever seen by calls made under its own context.  What follows:
  *           - every pointer of a parked request must stay valid until it has been carried, flushed
  *             (ultr_*_flush launches it on its own) or cancelled (ultr_*_cancel drops it);
- *           - parking a second request of a kind launches the first one on its own, at once;
+ *           - parking a second request of a kind in one context launches the first on its own, at once;
  *           - a loss request is only differentiated in place by a carrier whose d_scores / scores
  *             buffer and B*L are the request's own; any other carrier launches it on its own first
- *             (ultr_dnn_train_fused refuses instead).  Metric and assembly requests do not depend on
- *             the carrier's data and ride with whichever carrier of that thread comes next -- so with
- *             two models stepped alternately on one thread each request still runs exactly once,
- *             before or inside the next carrier, but an ASSEMBLY parked for model A is flushed early
- *             (into A's live batch buffers) if model B parks its own before A has stepped: step the
- *             models one whole step at a time, or do not prefetch;
- *           - a carrier called from ANOTHER thread does not see the request (flush it), and a
- *             carrier on another stream runs it on that stream, unordered against the stream the
- *             request's inputs were produced on;
+ *             (ultr_dnn_train_fused consumes it and refuses).  Metric and assembly requests do not
+ *             depend on the carrier's data and ride with whichever carrier of that context comes next;
+ *           - a context is plain host memory and not locked: two threads must not use one context at
+ *             the same time; a carrier under ANOTHER context (or another thread's default) does not see
+ *             the request, and a carrier on another stream runs it on that stream, unordered against
+ *             the stream the request's inputs were produced on;
  *           - the non-deferred twins of every call (ultr_loss_*_fwdbwd, ultr_metrics,
  *             ultr_batch_assemble) keep no state;
  *       (2) ultr_profile_* (process-wide event lists, off by default);
  *       (3) ultr_metrics_static (a per-device scratch array inside the library);
- *     and a handful of launch-plan experiment switches (ULTR_* environment variables)
- *     are read once per process, at first use;
+ *     and the launch-plan switches that remain (ULTR_* environment variables, DESIGN.md section 6:
+ *     each selects a plan that the tests run) are read once per process, at first use;
  *   - "position-major" [L][B]: element (list b, rank l) is at l*B + b, i.e. the row order of
  *     DNN.build's axis-0 concat (DNN.py:65);
  *   - a doc id equal to n_rows denotes the zero pad row (base_algorithm.py:120-123).
@@ -119,6 +121,19 @@ typedef struct UltrDnnDesc {
 int ultr_version(void);
 const char* ultr_last_error(void);
 
+/* Request contexts for the *_deferred calls (Conventions, "state between calls").  No counterpart in the
+ * reference: there a tf.Session owns the graph's deferred work, one per model; here the caller owns a context
+ * per model.  ultr_pending_create returns a new, empty context (NULL when out of host memory);
+ * ultr_pending_bind makes ctx the calling thread's current context and returns the one bound before (NULL = the
+ * thread's default context, also valid as an argument); ultr_pending_count returns how many requests are parked
+ * in ctx (NULL = the calling thread's default context); ultr_pending_destroy drops the context together with
+ * whatever is still parked in it (nothing is launched) and, if the calling thread had it bound, rebinds the
+ * thread's default.  Host-only calls: no stream, no device work. */
+void* ultr_pending_create(void);
+void* ultr_pending_bind(void* ctx);
+int ultr_pending_count(void* ctx);
+void ultr_pending_destroy(void* ctx);
+
 /* Opt-in per-kernel timing for bench.py's roofline line (no reference counterpart): when on, every
  * launch is bracketed by HIP events on its own stream.  ultr_profile_report synchronises and writes
  * "kernel_name count total_ms" lines into buf (host); returns the bytes written. */
@@ -184,7 +199,7 @@ int ultr_batch_assemble(const int* initial_list, const float* labels, int Q, int
                         float* out_clicks, int* out_list_idx, int* info, void* stream);
 
 /* ultr_batch_assemble (mode 0) with the launch deferred -- a prefetching feed: the request is parked and the NEXT
- * ultr_dnn_backward call of this host thread carries it as extra workgroups of its last launch, by which time
+ * ultr_dnn_backward call under the same request context carries it as extra workgroups of its last launch, by which time
  * nothing reads the current batch any more, so the output buffers may be the ones the current step is using
  * (click_simulation_feed.py:107-162 assembles a batch per get_batch call; here the call for batch t+1 is made
  * during step t).  The buffers must stay valid until the request has run.  ultr_batch_assemble_flush launches a parked request on its own; so does any later
@@ -261,7 +276,7 @@ int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const 
  * (the reference runs all of them in ONE session.run: DNN.py:63-96, dla.py:119-180 + 237-239 and the other algorithms'
  * graphs).  A workgroup owns whole lists and carries them through forward, d_score, and the dgrad / LayerNorm-backward
  * chain with every activation in LDS; one launch then forms every layer's weight gradient, one reduces the partials.
- *   The loss comes from the request parked by ultr_loss_{dla,ipw,ipw_table,rem,pd}_deferred on this host thread: its
+ *   The loss comes from the request parked by ultr_loss_{dla,ipw,ipw_table,rem,pd}_deferred in the bound request context: its
  *   `scores` must be this call's `scores` and its B, L this call's (ULTR_EINVAL otherwise; the request is consumed).
  *   The chain kernel evaluates d_score with the loss kernels' own lane functions (same bits) and writes scores and the
  *   list weights; the request's statistics (and d_scores, prop_grads, pw_out) are produced by rider workgroups of the
@@ -319,7 +334,7 @@ int ultr_loss_dla_fwdbwd(const float* scores, const float* clicks, int B, int L,
                          float* prop_grads, float* list_weights, float* stats, float* ws, void* stream);
 
 /* ultr_loss_dla_fwdbwd with the launch deferred: same arguments and results, but for L <= 16 nothing is launched
- * here -- the request is parked and the NEXT ultr_dnn_backward / ultr_dnn_backward_sumsq call of this host thread
+ * here -- the request is parked and the NEXT ultr_dnn_backward / ultr_dnn_backward_sumsq call under the same request context
  * carries it inside its FIRST launch, provided that call's d_scores is this request's d_scores and its M equals
  * B * L: the loss kernel's workgroups ride along (statistics, tower gradient, list weights, d_scores), and the
  * backward workgroups evaluate the d_score of their own rows from scores / clicks / prop_params instead of reading
@@ -336,7 +351,7 @@ int ultr_loss_cancel(void);
 /* The same for the IPW / naive loss (ultr_loss_ipw_fwdbwd: pw must be ready when the backward pass runs), the pairwise
  * debiasing loss (ultr_loss_pd_fwdbwd) and the regression-EM loss (ultr_loss_rem_fwdbwd: its d_score is elementwise, sigmoid(score + b) - Bernoulli label, so the
  * backward workgroups draw the label of each of their rows themselves, from the same Philox counter or the same
- * supplied uniforms).  At most one request is parked per host thread; parking a second one launches the first. */
+ * supplied uniforms).  At most one request is parked per request context; parking a second one launches the first. */
 int ultr_loss_ipw_deferred(const float* scores, const float* clicks, const float* pw, int B, int L, int loss_func,
                            float* d_scores, float* stats, float* list_weights, float* ws, void* stream);
 /* ultr_ipw_weights + ultr_loss_ipw_deferred in one request: the weights are formed from the clicks and the estimator's
@@ -384,8 +399,8 @@ int ultr_pd_update_ratios(float* t_plus, float* t_minus, int L, float* stats, fl
                           float regulation_p, float* old_out /* [2L] pre-update t+,t-; may be NULL */,
                           void* stream);
 
-/* The same two EM-state updates (regression_EM.py:151-155, pairwise_debias.py:162-171), parked on
- * the calling thread instead of launched: the next ultr_clip_adagrad* call on this thread carries
+/* The same two EM-state updates (regression_EM.py:151-155, pairwise_debias.py:162-171), parked in
+ * the bound request context instead of launched: the next ultr_clip_adagrad* call under it carries
  * the request in its update launch (workgroup 0 applies it before it publishes the step's row; a
  * parameter group of <= 4096 floats launches it first instead).  The pointers must stay valid
  * until that call.  A second request, or ultr_em_update_flush, launches a parked one on `stream`.
@@ -397,8 +412,8 @@ int ultr_pd_update_ratios_deferred(float* t_plus, float* t_minus, int L, float* 
 int ultr_em_update_flush(void* stream);
 
 /* The fused training step (ultr_dnn_train_fused) carries a parked metric evaluation as rider workgroups that stop at
- * their partial rows; the column sums, the division by B and the tie counter's bump are parked on the calling thread
- * for the next ultr_clip_adagrad* call, whose update launch performs them before it publishes (a parameter group of
+ * their partial rows; the column sums, the division by B and the tie counter's bump are parked in the bound request
+ * context for the next ultr_clip_adagrad* call, whose update launch performs them before it publishes (a parameter group of
  * <= 4096 floats: a one-workgroup launch first).  The metric outputs are therefore valid after that call, or after
  * ultr_metrics_tail_flush, which performs a parked reduction on `stream` at once (no-op when nothing is parked). */
 int ultr_metrics_tail_flush(void* stream);
@@ -416,7 +431,7 @@ int ultr_metrics(const float* scores, const float* labels, const int* docids, in
                  int n_topn, int metric_mask, float max_label, float* out, float* ws, void* stream);
 
 /* ultr_metrics with the launch deferred: same arguments and results, but for lists of at most 64 entries nothing
- * is launched here -- the request is parked and the NEXT ultr_dnn_backward call of this host thread carries it as
+ * is launched here -- the request is parked and the NEXT ultr_dnn_backward call under the same request context carries it as
  * extra workgroups of its largest weight-gradient launch (the in-step metrics of dla.py:189-221 need only the
  * scores and the list weights, which exist before the backward pass; riding along takes their latency out of the
  * chain of dependent launches).  All pointers must stay valid until that call.  Longer lists are evaluated at once.
@@ -490,6 +505,11 @@ int ultr_clip_adagrad2(float* theta, float* acc, const float* grads, long long n
  *   sumsq != NULL (and l2 == 0): the norm is formed from n_sumsq partial sums of squares of grads[0..n_covered)
  *     (ultr_dnn_backward_sumsq) plus the squares of grads[n_covered..n), n - n_covered <= 65536, instead of a
  *     pass over the gradient; the small group then rides with the update launch.
+ *   sumsq == NULL and n_sumsq == -1: no partials exist (data parallel: the gradient is final only after the
+ *     collective), and the update launch forms the norm ITSELF -- every update workgroup leaves the partial of its own
+ *     elements in ws, arrives at a counter (ws[0], which only ever grows: do not clear ws between calls) and waits
+ *     for the launch's other update workgroups (at most 1024, co-resident) -- instead of a norm launch before it.
+ *     With sumsq != NULL and l2 != 0 the same happens (the partials describe the raw gradient only).
  *   publish_n > 0: workgroup 0 copies publish_n floats publish_src -> publish_dst, with out_norm / out_norm_s
  *     taken fresh when they lie inside the source range.  publish_dst may be device memory or the device-side
  *     address of pinned host memory (ultr_host_device_pointer): the step's results row reaches the host without

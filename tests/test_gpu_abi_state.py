@@ -1,7 +1,8 @@
-"""GPU tests (-m gpu) of the library's parked per-thread requests (include/ultr_hip.h, Conventions): two models on
-one host thread, stepped alternately -- each with a prefetching feed, so loss, metric AND next-batch requests are
-parked and carried -- must train exactly as each does alone; and the phases of two steps may interleave when the
-feeds do not prefetch."""
+"""GPU tests (-m gpu) of the library's parked requests and their caller-owned contexts (include/ultr_hip.h,
+Conventions; ultr_pending_*): models on one host thread, stepped alternately -- each with a prefetching feed, so loss,
+metric AND next-batch requests are parked and carried -- must train exactly as each does alone, whole steps
+alternating or the phases of their steps interleaved; and a request parked under one context is invisible under
+another."""
 import numpy as np
 import pytest
 import torch
@@ -72,14 +73,18 @@ def test_models_stepped_alternately_on_one_thread_train_as_each_does_alone():
         assert_same(final_state(w), st, w['losses'], losses)
 
 
-def test_phases_of_two_steps_interleave_when_the_feeds_do_not_prefetch():
+@pytest.mark.parametrize('prefetch', [False, True])
+def test_phases_of_steps_interleave(prefetch):
+    """get_batch of every model, then step_local of every model, the collectives in reverse order, then every update:
+    each model's requests (with prefetch=True also the next batch's assembly, parked during get_batch and carried by
+    the model's own backward pass two phases later) live in the model's own context."""
     solo = []
-    for spec in SPECS[:3]:
-        w = build(spec, prefetch=False)
+    for spec in SPECS:
+        w = build(spec, prefetch=prefetch)
         for _ in range(3):
             whole_step(w)
         solo.append((final_state(w), w['losses']))
-    worlds = [build(spec, prefetch=False) for spec in SPECS[:3]]
+    worlds = [build(spec, prefetch=prefetch) for spec in SPECS]
     for _ in range(3):
         feeds = []
         for w in worlds:
@@ -94,3 +99,35 @@ def test_phases_of_two_steps_interleave_when_the_feeds_do_not_prefetch():
             w['losses'].append((float(loss), summ.as_dict()))
     for w, (st, losses) in zip(worlds, solo):
         assert_same(final_state(w), st, w['losses'], losses)
+
+
+def test_a_request_is_seen_only_under_its_own_context():
+    from ultra_amd import _lib as L
+    lib = L.lib()
+    a, b = L.PendingContext(), L.PendingContext()
+    B, Lr = 8, 5
+    scores = torch.randn(Lr, B, device='cuda')
+    labels = (torch.rand(Lr, B, device='cuda') < 0.3).float()
+    out = torch.zeros(8, device='cuda')
+    topn = (L.ctypes.c_int * 1)(3)
+    ws = torch.zeros(int(lib.ultr_metrics_workspace_floats(B, 1)), device="cuda")
+    was = lib.ultr_pending_bind(a.handle)
+    try:
+        L.check(lib.ultr_metrics_deferred(L.ptr(scores), L.ptr(labels), None, 0, None, None, B, Lr, topn, 1, 2, 1.0,
+                                          L.ptr(out), L.ptr(ws), L.current_stream()), 'ultr_metrics_deferred')
+        assert a.count() == 1 and b.count() == 0
+        b.bind()
+        assert lib.ultr_metrics_cancel() == 0          # nothing parked HERE
+        L.check(lib.ultr_metrics_flush(L.current_stream()))
+        torch.cuda.synchronize()
+        assert float(out.abs().sum()) == 0.0           # and nothing ran
+        a.bind()
+        L.check(lib.ultr_metrics_flush(L.current_stream()))
+        torch.cuda.synchronize()
+        assert a.count() == 0 and float(out.abs().sum()) > 0.0
+        h = lib.ultr_pending_create()
+        lib.ultr_pending_bind(h)
+        lib.ultr_pending_destroy(h)                    # the bound context goes away: the thread's default takes over
+        assert lib.ultr_pending_bind(None) is None
+    finally:
+        lib.ultr_pending_bind(was)

@@ -1,6 +1,6 @@
 """GPU tests (-m gpu) of the PRODUCT's data-parallel step with two ranks' worth of state on one GPU: two algorithm
-instances with world = 2 and rank = 0 / 1 forced (no process group), B lists each; `step_local` on both, the first
-`n_reduce` floats of the two buckets summed by hand and written back to both (what the one RCCL all-reduce does),
+instances with world = 2 and rank = 0 / 1 forced (no process group), B lists each; `step_local` on both, the reduced
+range of the two buckets (`_train_bufs['reduce']`) summed by hand and written back to both (what the one RCCL all-reduce does),
 `step_apply` on both -- against ONE instance stepping the 2B-list batch.  Clicks / doc ids bit-exact (slot s of rank r
 is global slot r*B + s of the Philox stream), parameters, EM state, loss and every summary to 1e-6 relative with a
 small absolute floor on the first step (same variables on both sides, fp32 sums in another order), 2e-5 on the later
@@ -65,11 +65,10 @@ def test_two_ranks_on_one_gpu_equal_one_rank_with_the_whole_batch(algo, hp, mhp,
         lw, _, sw = whole.step(None, fw, False)
         for (m, _), fr in zip(ranks, feeds):
             m.step_local(fr)
-        n = ranks[0][0]._train_bufs['n_reduce']
-        total = ranks[0][0]._train_bufs['bucket'][:n] + ranks[1][0]._train_bufs['bucket'][:n]
+        total = ranks[0][0]._train_bufs['reduce'] + ranks[1][0]._train_bufs['reduce']  # what the collective would leave
         outs = []
         for m, _ in ranks:
-            m._train_bufs['bucket'][:n].copy_(total)
+            m._train_bufs['reduce'].copy_(total)
             outs.append(m.step_apply())
         want = sw.as_dict()
         for r, (lr, _, sr) in enumerate(outs):

@@ -902,11 +902,11 @@ def test_dnn_build_reference_api(L):
     assert DNN('norm=batch').create_variables(8, 'cuda') is not None  # batch normalisation: tests/test_gpu_batchnorm.py
 
 
-@pytest.mark.parametrize('env', [{'ULTR_FWD_CHAIN': '0'}, {'ULTR_BWD_CHAIN': '1'}, {'ULTR_BWD_PAIR': '3'},
+@pytest.mark.parametrize('env', [{'ULTR_FWD_CHAIN': '0'}, {'ULTR_BWD_CHAIN': '1'},
                                  {'ULTR_METRICS_RIDE': '0'}, {'ULTR_FUSED_TAIL': '0'}, {'ULTR_LOSS_RIDE': '0'}])
 def test_alternate_kernel_paths_in_a_fresh_process(env):
     """The library picks its launch plan from the shapes; the plans that the default shapes no longer reach (per-layer
-    forward kernels, the backward chain, paired wgrad+dgrad for every layer, a metric launch of its own, norm pass and result copy as launches of their own) are switched
+    forward kernels, the backward chain, a metric launch of its own, norm pass and result copy as launches of their own) are switched
     on through their environment variables -- read once per process, hence the subprocess -- and must pass the same
     DNN forward/backward and training-step parity tests."""
     import subprocess

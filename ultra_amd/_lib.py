@@ -6,6 +6,7 @@ entry point returns a negative code.
 """
 import ctypes
 import os
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libultr_hip.so')
@@ -57,6 +58,10 @@ _DESC = ctypes.POINTER(UltrDnnDesc)
 SIGNATURES = {
     'ultr_version': (_I, []),
     'ultr_last_error': (ctypes.c_char_p, []),
+    'ultr_pending_create': (_P, []),
+    'ultr_pending_bind': (_P, [_P]),
+    'ultr_pending_count': (_I, [_P]),
+    'ultr_pending_destroy': (None, [_P]),
     'ultr_profile_enable': (_I, [_I]),
     'ultr_profile_report': (_I, [ctypes.c_char_p, _I]),
     'ultr_ln_row_stats': (_I, [_P, _LL, _I, _I, _F, _P, _P]),
@@ -146,6 +151,45 @@ def check(rc, what=''):
     if rc < 0:
         raise UltrError('%s failed (%d): %s' % (what, rc, lib().ultr_last_error().decode()))
     return rc
+
+
+def _destroy_context(handle):
+    if _lib is not None:
+        _lib.ultr_pending_destroy(handle)
+
+
+class PendingContext(object):
+    """A caller-owned context for the library's parked (*_deferred) requests: ultr_pending_create / _bind / _destroy
+    (include/ultr_hip.h, Conventions).  Every learning algorithm owns one and binds it before the calls it makes for
+    itself, and so do the feeds built for it, so models stepped alternately on one host thread never see each other's
+    requests.  ``PendingContext(None)`` stands for the calling thread's own default context."""
+
+    def __init__(self, handle='new'):
+        self.assemble_owner = None  # id() of the feed whose next-batch request was parked here last
+        if handle == 'new':
+            h = lib().ultr_pending_create()
+            if not h:
+                raise UltrError('ultr_pending_create: out of host memory')
+            self.handle = ctypes.c_void_p(h)
+            self._fin = weakref.finalize(self, _destroy_context, self.handle)
+            self._fin.atexit = False  # at interpreter shutdown the feeds may still want to cancel into it
+        else:
+            self.handle = handle
+
+    def bind(self):
+        """Make this the calling thread's current context (it stays bound until another one is)."""
+        lib().ultr_pending_bind(self.handle)
+
+    def count(self):
+        return lib().ultr_pending_count(self.handle)
+
+
+_thread_default = PendingContext(None)
+
+
+def context_of(model):
+    """The request context of a learning algorithm (the thread's default for anything that has none)."""
+    return getattr(model, 'pending_ctx', None) or _thread_default
 
 
 def ptr(t):

@@ -1753,14 +1753,6 @@ static int launch_fwd_layer(const FwdArgs& a, bool fuse, hipStream_t st, const c
     return WK == 1 ? launch_fwd<4, 1, true>(a, st, name) : launch_fwd<4, 2, true>(a, st, name);
   }
   const long long base = tilesM * tilesN;
-  static const char* const v = getenv("ULTR_FWD_VARIANT");  // experiment switch, read once: "41", "22", "14", "42", "81"
-  if (v) {
-    if (!strcmp(v, "41")) return launch_fwd<4, 1, false>(a, st, name);
-    if (!strcmp(v, "22")) return launch_fwd<2, 2, false>(a, st, name);
-    if (!strcmp(v, "14")) return launch_fwd<1, 4, false>(a, st, name);
-    if (!strcmp(v, "42")) return launch_fwd<4, 2, false>(a, st, name);
-    if (!strcmp(v, "81")) return launch_fwd<8, 1, false>(a, st, name);
-  }
   // measured at M = 2560 (tools/kbench, rocprofv3): layer 0 (K136 N512) 8x1 13.1 us, 4x1 14.7, 4x2 18.5, 2x2 20.7;
   // layer 1 (K512 N256) 4x2 18.7 us, 2x2 21.7, 4x1 22.8, 8x1 32.5 -- wider workgroups share one staged panel
   if (base >= 1024 || chunks < 4) return tilesN >= 8 ? launch_fwd<8, 1, false>(a, st, name) : launch_fwd<4, 1, false>(a, st, name);
@@ -2075,14 +2067,11 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   // Per layer: wgrad_j, dgrad_j, then the row pass that turns dh into dz_{j-1}.  The two GEMMs of a layer can run
   // side by side in one launch (bwd_pair_kernel).  For the big layer the pair costs the SUM of its parts -- both
   // are bound by the memory side feeding just-written data, not by latency -- so only small layers are paired.
-  // ULTR_BWD_PAIR=<mask> (bit j-1: layer j) overrides the rule below; measured at M = 2560: pairing layer 2
-  // (K256 N128) 13.9 us against 9.4 + 8.8, pairing layer 1 (K512 N256) 34.0 us against 14.9 + 17.5
-  static const int pair_env = [] { const char* e = getenv("ULTR_BWD_PAIR"); return e ? atoi(e) : -1; }();
+  // Measured at M = 2560: pairing layer 2 (K256 N128) 13.9 us against 9.4 + 8.8, pairing layer 1 (K512 N256) 34.0 us
+  // against 14.9 + 17.5
   int pair_mask = 0;
-  if (pair_env >= 0) pair_mask = pair_env;
-  else
-    for (int j = 1; j < H; ++j)  // small GEMMs only: they leave most of the chip idle on their own
-      if (2.0 * (double)M * L.K[j] * L.N[j] <= 0.25e9) pair_mask |= 1 << (j - 1);
+  for (int j = 1; j < H; ++j)  // small GEMMs only: they leave most of the chip idle on their own
+    if (2.0 * (double)M * L.K[j] * L.N[j] <= 0.25e9) pair_mask |= 1 << (j - 1);
   if (bn) pair_mask = 0;  // the normalisation's column sums sit between dgrad and the row pass
   if (L.wgall) pair_mask = 0;  // the weight gradients come after the dgrad chain, in one launch
   // A parked metric request (ultr_metrics_deferred) rides with layer 0's weight-gradient launch.  Measured at the
@@ -2125,8 +2114,6 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   int carrier = -1;
   if (g_pending_metrics.on) {
     if (H >= 1 && g_pending_metrics.nblocks <= 64 && !L.wgall) carrier = 0;  // a bigger request is no rider: a launch of its own
-    static const int carrier_env = [] { const char* e = getenv("ULTR_RIDE_CARRIER"); return e ? atoi(e) : -1; }();  // experiments
-    if (carrier_env >= 0 && carrier_env < H && !pair_mask) carrier = carrier_env;
     if (carrier < 0) {
       g_pending_metrics.on = false;
       rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, st);

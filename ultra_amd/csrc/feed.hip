@@ -644,7 +644,6 @@ extern "C" int ultr_click_cascade(const float* labels, long long n, int L, const
 }
 
 namespace ultr {
-thread_local PendingAssemble g_pending_assemble = {};
 
 int launch_assemble_now(const AssembleArgs& a, unsigned nblocks, hipStream_t st) {
   {

@@ -201,13 +201,14 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
 }
 
 
-// A request parked by ultr_batch_assemble_deferred until the next ultr_dnn_backward of this host thread carries it.
+// A request parked by ultr_batch_assemble_deferred until the next ultr_dnn_backward under the same request context carries it.
 struct PendingAssemble {
   bool on;
   AssembleArgs a;
   unsigned nblocks;
 };
-extern thread_local PendingAssemble g_pending_assemble;
+PendingAssemble& pending_assemble();  // of the calling thread's bound request context (optim.hip)
+#define g_pending_assemble (::ultr::pending_assemble())
 int launch_assemble_now(const AssembleArgs& a, unsigned nblocks, hipStream_t st);  // feed.hip
 
 }  // namespace ultr

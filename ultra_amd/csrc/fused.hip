@@ -1331,7 +1331,7 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   };
   long long tiles = 0;
   for (int j = 0; j < P.H; ++j) tiles += cdiv(P.K[j], 64) * cdiv(P.N[j], 64);
-  static const int wg_target = [] { const char* e = getenv("ULTR_WG_TARGET"); return e ? atoi(e) : 512; }();
+  constexpr int wg_target = 512;  // two workgroups per CU (measured against 256, 384 and 768 at the headline shape)
   long long ns = wg_target / tiles;
   if (ns < 1) ns = 1;
   if (ns > cdiv(M, 64)) ns = cdiv(M, 64);
@@ -1664,6 +1664,7 @@ extern "C" int ultr_clip_adagrad_fused(const UltrDnnDesc* desc, int B, int L, vo
     r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
   }
   TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}, AssembleArgs{}, 0, 0};
+  if (!sumsq && n_sumsq == -1) { o.n_sumsq = 0; o.grid_norm = 1; }  // no partials: the update launch forms the norm itself
   // (a parked assembly of the next batch rides with the update: clip_adagrad_impl takes it once its checks have passed)
   float* wsf = reinterpret_cast<float*>(workspace);
   for (int j = P.bf16 ? 0 : 1; j < P.H; ++j) {

@@ -496,7 +496,6 @@ __global__ void pd_update_kernel(float* t_plus, float* t_minus, int L, float* st
 using namespace ultr;
 
 namespace ultr {
-thread_local PendingLoss g_pending_loss = {};
 
 static inline unsigned small_blocks(int B) { return (unsigned)(cdiv(B, 16) < 1024 ? cdiv(B, 16) : 1024); }
 
@@ -759,7 +758,6 @@ extern "C" int ultr_loss_rem_deferred(const float* scores, const float* clicks, 
 }
 
 namespace ultr {
-thread_local PendingEm g_pending_em = {};
 __global__ void __launch_bounds__(64) em_update_kernel(EmUpdate e) {
   if (e.kind == ULTR_RIDE_REM) rem_update_body(e);
   else pd_update_body(e);

@@ -748,7 +748,7 @@ __device__ __forceinline__ void pd_loss_small_body(const PdArgs& a, unsigned int
   }
 }
 
-// A loss request parked by ultr_loss_{dla,ipw,rem,pd}_deferred until the next ultr_dnn_backward of this host thread
+// A loss request parked by ultr_loss_{dla,ipw,rem,pd}_deferred until the next ultr_dnn_backward under the same request context
 // carries it in its first launch.
 enum { ULTR_RIDE_NONE = 0, ULTR_RIDE_DLA = 1, ULTR_RIDE_IPW = 2, ULTR_RIDE_REM = 3, ULTR_RIDE_PD = 4 };
 
@@ -807,7 +807,8 @@ __device__ __forceinline__ void pd_update_body(const EmUpdate& e) {
   }
 }
 struct PendingEm { bool on; EmUpdate e; };
-extern thread_local PendingEm g_pending_em;
+PendingEm& pending_em();  // of the calling thread's bound request context (optim.hip)
+#define g_pending_em (::ultr::pending_em())
 int launch_em_now(const EmUpdate& e, hipStream_t st);  // loss.hip
 
 struct PendingLoss {
@@ -825,7 +826,8 @@ struct PendingLoss {
            : kind == ULTR_RIDE_REM ? (long long)rem.B * rem.L : (long long)pd.B * pd.L;
   }
 };
-extern thread_local PendingLoss g_pending_loss;
+PendingLoss& pending_loss();
+#define g_pending_loss (::ultr::pending_loss())
 int launch_loss_now(const PendingLoss& p, hipStream_t st);  // loss.hip
 
 }  // namespace ultr

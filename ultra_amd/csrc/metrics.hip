@@ -389,8 +389,6 @@ extern "C" long long ultr_metrics_workspace_floats(int B, int n_topn) {
 }
 
 namespace ultr {
-thread_local PendingMetrics g_pending_metrics = {};
-thread_local PendingMetricsTail g_pending_mtail = {};
 
 __global__ void __launch_bounds__(kMetThreads) metrics_tail_kernel(MetricsTail t) {
   __shared__ float s_tmp[kMetThreads];

@@ -45,7 +45,8 @@ __device__ __forceinline__ void metrics_tail_body(const MetricsTail& t, float* s
   if (tid == 0 && t.tie_ctr) __hip_atomic_fetch_add(t.tie_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 struct PendingMetricsTail { bool on; MetricsTail t; };
-extern thread_local PendingMetricsTail g_pending_mtail;
+PendingMetricsTail& pending_mtail();  // of the calling thread's bound request context (optim.hip)
+#define g_pending_mtail (::ultr::pending_mtail())
 int launch_metrics_tail_now(const MetricsTail& t, hipStream_t st);  // metrics.hip
 
 __device__ __forceinline__ unsigned int tie_step_of(const MetricsArgs& a) {
@@ -294,13 +295,14 @@ __device__ __forceinline__ void metrics_finish(const MetricsArgs& a, int bid, in
   }
 }
 
-// A metric request parked by ultr_metrics_deferred until the next ultr_dnn_backward of this host thread carries it.
+// A metric request parked by ultr_metrics_deferred until the next ultr_dnn_backward under the same request context carries it.
 struct PendingMetrics {
   bool on;
   MetricsArgs a;
   unsigned nblocks;
 };
-extern thread_local PendingMetrics g_pending_metrics;
+PendingMetrics& pending_metrics();
+#define g_pending_metrics (::ultr::pending_metrics())
 int launch_metrics_now(const MetricsArgs& a, unsigned nblocks, hipStream_t st);  // metrics.hip
 
 }  // namespace ultr

@@ -6,6 +6,8 @@
 //
 // HBM-bound: 20 B per parameter per step (read g, acc, theta; write acc, theta) + 8 B for the
 // norm pass (g, theta re-read, L2-resident for the DNN's <= 2 MB of parameters).
+#include <new>
+
 #include "optim_shared.hpp"
 
 namespace ultr {
@@ -131,6 +133,39 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
     for (long long i = o.n_covered + threadIdx.x; i < n; i += blockDim.x) ssq[0] += grads[i] * grads[i];
     block_sum<1>(ssq, red);
     nrm = fabsf(sc) * sqrtf(ssq[0]);
+  } else if (o.grid_norm) {
+    // ---- the norm, formed inside this launch: partial of the elements this workgroup updates ...
+    float part[1] = {0.f};
+    for (long long i = i0; i < n4; i += nblk * blockDim.x) {
+      const float4 g = i == i0 ? g0 : g4[i];
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l2 != 0.f) t = i == i0 ? t0 : t4[i];
+      const float a = g.x * sc + l2 * t.x, b = g.y * sc + l2 * t.y, c = g.z * sc + l2 * t.z, d = g.w * sc + l2 * t.w;
+      part[0] += a * a + b * b + c * c + d * d;
+    }
+    if (bid == 0 && threadIdx.x < (n & 3)) {
+      const long long i = (n4 << 2) + threadIdx.x;
+      const float a = grads[i] * sc + (l2 != 0.f ? l2 * theta[i] : 0.f);
+      part[0] += a * a;
+    }
+    block_sum<1>(part, red);
+    // ... published write-through, then the launch-wide rendezvous: the counter only ever grows (it is never reset, so
+    // a replayed graph needs no memset); the arrivals of one launch share the target (old / nblk + 1) * nblk because a
+    // stream runs its launches in order.  (2^32 arrivals, some 10^7 steps, would wrap it: not handled.)
+    float* wsw = const_cast<float*>(ws);
+    if (threadIdx.x == 0) {
+      st_agent(wsw + 8 + bid, part[0]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned int* ctr = reinterpret_cast<unsigned int*>(wsw);
+      const unsigned int nb = (unsigned int)nblk;
+      const unsigned int old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int target = (old / nb + 1u) * nb;
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n_partials; p += blockDim.x) ssq[0] += ld_agent(ws + 8 + p);
+    block_sum<1>(ssq, red);
+    nrm = sqrtf(ssq[0]);
   } else {
     for (int p = threadIdx.x; p < n_partials; p += blockDim.x) ssq[0] += ws[8 + p];
     block_sum<1>(ssq, red);
@@ -225,7 +260,10 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
     ULTR_REQUIRE(ws, ULTR_EINVAL, "ultr_clip_adagrad: workspace required");
     ULTR_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grads % 16 == 0) && (!acc || (uintptr_t)acc % 16 == 0),
                  ULTR_EINVAL, "ultr_clip_adagrad: buffers must be 16-byte aligned");
-    if (l2 != 0.f) o.sumsq = nullptr;  // the partials are of the raw gradient: with an l2 term the norm pass runs
+    if (l2 != 0.f && o.sumsq) {  // the partials are of the raw gradient: with an l2 term the launch forms the norm itself
+      o.sumsq = nullptr;
+      o.grid_norm = 1;
+    }
     ULTR_REQUIRE(!o.sumsq || (o.n_sumsq > 0 && o.n_covered >= 0 && o.n_covered <= n && n - o.n_covered <= 65536), ULTR_EINVAL,
                  "ultr_clip_adagrad3: bad sum-of-squares partials (n_sumsq=%d n_covered=%lld)", o.n_sumsq, o.n_covered);
     ULTR_REQUIRE(o.pub_n == 0 || (o.pub_src && o.pub_dst && o.pub_n > 0), ULTR_EINVAL, "ultr_clip_adagrad3: bad publish range");
@@ -265,7 +303,7 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
   if (blocks > kOptMaxBlocks) blocks = kOptMaxBlocks;
   if (blocks < 1) blocks = 1;
   SmallGroup none{};
-  if (!o.sumsq) {
+  if (!o.sumsq && !o.grid_norm) {
     {
       ultr::ProfScope prof_("gnorm_partial_kernel", as_stream(stream));
       hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)(blocks + (rider.n > 0 ? 1 : 0))), dim3(kOptThreads), 0,
@@ -274,7 +312,7 @@ int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n,
     int rc = check_launch("gnorm_partial_kernel");
     if (rc) return rc;
   }
-  const SmallGroup& apply_rider = o.sumsq ? rider : none;  // no norm launch: the small group rides with the update
+  const SmallGroup& apply_rider = (o.sumsq || o.grid_norm) ? rider : none;  // no norm launch: the small group rides with the update
   {
     ultr::ProfScope prof_("adagrad_apply_kernel", as_stream(stream));
     hipLaunchKernelGGL(adagrad_apply_kernel, dim3((unsigned)(blocks + (apply_rider.n > 0 ? 1 : 0) + o.a_pad)), dim3(kOptThreads), 0,
@@ -316,5 +354,50 @@ extern "C" int ultr_clip_adagrad3(float* theta, float* acc, const float* grads, 
     r = SmallGroup{theta_s, acc_s, grads_s, n_s, denom_s, scale_const_s, l2_s, clip_norm_s, lr_s, strategy, out_norm_s};
   }
   TailOpts o{sumsq, n_sumsq, n_covered, publish_src, publish_dst, publish_n, TransposeOpts{}, AssembleArgs{}, 0, 0};
+  if (!sumsq && n_sumsq == -1) { o.n_sumsq = 0; o.grid_norm = 1; }  // no partials: the update launch forms the norm itself
   return clip_adagrad_impl(theta, acc, grads, n, denom, scale_const, l2, clip_norm, lr, strategy, out_norm, ws, r, o, stream);
+}
+
+// ---- parked-request contexts ---------------------------------------------------------------------------------------
+// Every *_deferred call parks its request in the calling thread's BOUND context: the thread's own default context, or
+// one the caller made (ultr_pending_create) and bound (ultr_pending_bind).  One context per model keeps the requests of
+// models stepped alternately on one host thread apart (ultr_hip.h, Conventions).
+namespace ultr {
+struct PendingSet {
+  PendingLoss loss;
+  PendingEm em;
+  PendingMetrics metrics;
+  PendingMetricsTail mtail;
+  PendingAssemble assemble;
+};
+static thread_local PendingSet t_default_set = {};
+static thread_local PendingSet* t_bound = nullptr;  // nullptr: the default set
+static inline PendingSet* cur_set() { return t_bound ? t_bound : &t_default_set; }
+PendingLoss& pending_loss() { return cur_set()->loss; }
+PendingEm& pending_em() { return cur_set()->em; }
+PendingMetrics& pending_metrics() { return cur_set()->metrics; }
+PendingMetricsTail& pending_mtail() { return cur_set()->mtail; }
+PendingAssemble& pending_assemble() { return cur_set()->assemble; }
+}  // namespace ultr
+
+extern "C" void* ultr_pending_create(void) {
+  return new (std::nothrow) ultr::PendingSet();
+}
+
+extern "C" void* ultr_pending_bind(void* ctx) {
+  void* was = ultr::t_bound;
+  ultr::t_bound = static_cast<ultr::PendingSet*>(ctx);
+  return was;
+}
+
+extern "C" int ultr_pending_count(void* ctx) {
+  const ultr::PendingSet* s = ctx ? static_cast<const ultr::PendingSet*>(ctx) : &ultr::t_default_set;
+  return (s->loss.kind != ULTR_RIDE_NONE) + (s->em.on ? 1 : 0) + (s->metrics.on ? 1 : 0) + (s->mtail.on ? 1 : 0) +
+         (s->assemble.on ? 1 : 0);
+}
+
+extern "C" void ultr_pending_destroy(void* ctx) {
+  if (!ctx) return;
+  if (ultr::t_bound == ctx) ultr::t_bound = nullptr;  // this thread falls back to its own; other threads: the caller's job
+  delete static_cast<ultr::PendingSet*>(ctx);
 }

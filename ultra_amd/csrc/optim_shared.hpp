@@ -59,6 +59,12 @@ struct TailOpts {
   // mt.nb > 0: the column sums of a metric evaluation whose rider workgroups left only partial rows (the fused step's
   // slab-reduction launch), formed by workgroup 0 before it publishes
   MetricsTail mt;
+  // grid_norm != 0 (no sumsq): the launch forms the gradient norm itself -- every update workgroup leaves the partial
+  // of its own elements, arrives at a counter (ws[0]) and waits for the launch's other update workgroups before it reads
+  // all partials in fixed order.  For gradients that are final only just before the update (data parallel: after the
+  // collective; an l2 term): one launch instead of a norm launch + an update launch.  The update workgroups (at most
+  // 1024 of 256 threads) are co-resident on the chip, so the wait cannot starve a workgroup it is waiting for.
+  int grid_norm;
 };
 
 int clip_adagrad_impl(float* theta, float* acc, const float* grads, long long n, const float* denom, float scale_const,

@@ -72,25 +72,28 @@ class ClickSimulationFeed(BaseInputFeed):
         self._out = {}
         # prefetch: (data set, batch size, check_validation) the buffers were last filled / parked for
         self._prefetched = None
+        self.ctx = _lib.context_of(model)  # where this feed's next-batch requests are parked
 
-    # The library parks ONE assembly request per host thread (include/ultr_hip.h, Conventions); several feeds may live
-    # on a thread, so the feeds remember whose request was parked last: a feed drops only its own request, and launches
-    # (never drops) one that may belong to another feed.
-    _parked_owner = None  # id() of the feed that parked last
-
+    # The library parks ONE assembly request per request context (include/ultr_hip.h, Conventions): the feed parks in
+    # its model's context (``self.ctx``), where the model's backward pass or update finds it.  Several feeds may serve
+    # one model, so the context remembers whose request was parked last: a feed drops only its own request, and
+    # launches (never drops) one that may belong to another feed of the same model.
     def _drop_parked(self):
         lib = _lib.lib()
-        if ClickSimulationFeed._parked_owner == id(self):
+        if self.ctx.assemble_owner == id(self):
             lib.ultr_batch_assemble_cancel()
         else:  # another feed's next batch (or nothing at all): it runs now, on its own
             _lib.check(lib.ultr_batch_assemble_flush(_lib.current_stream()), 'ultr_batch_assemble_flush')
-        ClickSimulationFeed._parked_owner = None
+        self.ctx.assemble_owner = None
 
     def __del__(self):
         try:
-            if self._prefetched is not None and ClickSimulationFeed._parked_owner == id(self):
-                _lib.lib().ultr_batch_assemble_cancel()  # the parked request points into buffers that go away with us
-                ClickSimulationFeed._parked_owner = None
+            if self._prefetched is not None and self.ctx.assemble_owner == id(self):
+                lib = _lib.lib()
+                was = lib.ultr_pending_bind(self.ctx.handle)
+                lib.ultr_batch_assemble_cancel()  # the parked request points into buffers that go away with us
+                lib.ultr_pending_bind(was)
+                self.ctx.assemble_owner = None
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
@@ -183,11 +186,12 @@ class ClickSimulationFeed(BaseInputFeed):
             # parks the request for the batch after it.  Host-side views of a batch (input_list, click_list, the
             # per-position feed entries) must therefore be read before the step that follows this call.
             key = (id(dd), B, bool(check_validation))
+            self.ctx.bind()
             if self._prefetched != key:
                 self._drop_parked()  # a request this feed parked for other arguments is dropped
                 self._assemble(dd, o, B, 0, check_validation=check_validation)
             self._assemble_deferred(dd, o, B, check_validation)
-            ClickSimulationFeed._parked_owner = id(self)
+            self.ctx.assemble_owner = id(self)
             self._prefetched = key
         elif self.hparams.device_rng:
             self._assemble(dd, o, B, 0, check_validation=check_validation)

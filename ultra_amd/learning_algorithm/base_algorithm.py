@@ -128,6 +128,7 @@ class BaseAlgorithm(ABC):
         if not torch.cuda.is_available():
             raise _lib.UltrError('ultra_amd needs an MI355X (HIP) device: there is no CPU path')
         _lib.lib()
+        self.pending_ctx = _lib.PendingContext()       # this model's parked requests (include/ultr_hip.h, Conventions)
         self.device = torch.device('cuda', torch.cuda.current_device())
         # feed-dict keys (dla.py:85-94)
         self.is_training = Placeholder('is_train')
@@ -221,7 +222,15 @@ class BaseAlgorithm(ABC):
         n0, n1 = self.n_total, self.n_total + self.n_stats
         n_bucket = n1 + n_met + self.N_LOCAL
         tb = {'B': B}
-        tb['bucket'] = torch.zeros(n_bucket, dtype=torch.float32, device=dev)
+        # Data parallel: the in-step metrics' partial rows (the metric workspace) sit directly in FRONT of the bucket, so
+        # that the step's one all-reduce carries them as well: column sums are additive, and the update launch adds the
+        # all-reduced rows exactly as it adds one rank's rows -- no launch of its own before the collective.
+        n_ws = int(_lib.lib().ultr_metrics_workspace_floats(B, len(self.train_plan.topn)))
+        tb['met_rows_reduced'] = self._dp_plan() and n_ws <= 16384
+        pre = (n_ws + 63) // 64 * 64 if tb['met_rows_reduced'] else 0
+        full = torch.zeros(pre + n_bucket, dtype=torch.float32, device=dev)
+        tb['bucket'] = full[pre:]
+        tb['reduce'] = full[:pre + n1 + n_met]       # what the collective sums: [metric rows | grads | stats | metrics]
         tb['grads'] = tb['bucket'][:n0]
         tb['stats'] = tb['bucket'][n0:n1]
         tb['metrics'] = tb['bucket'][n1:n1 + n_met]
@@ -231,7 +240,7 @@ class BaseAlgorithm(ABC):
         tb['d_scores'] = torch.empty((L, B), dtype=torch.float32, device=dev)
         tb['list_weights'] = torch.empty(B, dtype=torch.float32, device=dev)
         tb['loss_ws'] = torch.zeros(_lib.lib().ultr_loss_workspace_floats(B, L), dtype=torch.float32, device=dev)
-        tb['met_ws'] = dev_metrics.metrics_workspace(B, self.train_plan, dev)
+        tb['met_ws'] = full[:n_ws] if tb['met_rows_reduced'] else dev_metrics.metrics_workspace(B, self.train_plan, dev)
         tb['sumsq'] = torch.zeros(self.model.sumsq_count(), dtype=torch.float32, device=dev)
         tb['host_dev'] = None  # device-side addresses of the pinned result slots, looked up on first use
         n_host = self.n_stats + n_met + self.N_LOCAL
@@ -252,8 +261,15 @@ class BaseAlgorithm(ABC):
             s = self._side = torch.cuda.Stream(device=self.device)
         return s
 
+    # True: take the data-parallel launch plan (gradient norm inside the update launch, metric rows inside the reduced
+    # range) even with one rank -- bench.py's one-GPU rehearsal of the multi-GPU launch path sets it.
+    force_dp_plan = False
+
+    def _dp_plan(self):
+        return self.world > 1 or self.force_dp_plan
+
     def _all_reduce(self, tb):
-        parallel.all_reduce_bucket(tb['bucket'], tb['n_reduce'], self.world)
+        parallel.all_reduce_bucket(tb['reduce'], tb['reduce'].numel(), self.world)
 
     # ULTR_METRICS_RIDE=0: the metric kernel gets a launch of its own instead of riding with the backward pass
     ride_metrics = os.environ.get('ULTR_METRICS_RIDE', '1') != '0'
@@ -286,6 +302,7 @@ class BaseAlgorithm(ABC):
         if not self.fused_tail:
             return None
         tail = {'sumsq': tb['sumsq'] if tb.get('sumsq_valid') else None, 'n_covered': self.n_params,
+                'grid_norm': self._dp_plan(),  # the gradient is final only after the collective: norm inside the update launch
                 'fused': self.model.fused_update_target() if tb.get('fused') else None}
         if tb['host_dev'] is None:
             base = _lib.host_device_ptr(tb['host'])
@@ -362,6 +379,7 @@ class BaseAlgorithm(ABC):
 
     def step_local(self, input_feed):
         """Everything before the collective: scores, loss + d_scores, in-step metrics, flat un-normalised gradient."""
+        self.pending_ctx.bind()
         if self.world > 1 and not getattr(self, '_replicas_synced', False):
             self.sync_replicas()
         L = self.rank_list_size
@@ -411,13 +429,13 @@ class BaseAlgorithm(ABC):
         try:
             self._loss(tb, batch, scores)                      # parked: the fused call differentiates it
             self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS, deferred=True)
-            tb['sumsq_valid'] = self.fused_tail and self.world == 1
+            tb['sumsq_valid'] = self.fused_tail and not self._dp_plan()
             self.model.train_fused(batch.table, batch.table_stats, batch.n_rows, batch.docids[:self.rank_list_size],
                                    scores, tb['grads'], tb['sumsq'] if tb['sumsq_valid'] else None)
             _lib.check(lib.ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
-            if self.world > 1:
-                # the fused step leaves the metrics' column sums to the update launch; the collective in between reads
-                # them, so with several ranks they are formed now
+            if self._dp_plan() and not tb['met_rows_reduced']:
+                # the fused step leaves the metrics' column sums to the update launch; when the partial rows are too many
+                # to travel with the collective, the sums are formed now and travel instead
                 _lib.check(lib.ultr_metrics_tail_flush(_lib.current_stream()), 'ultr_metrics_tail_flush')
             self._after_scores(tb, batch, scores)
         except Exception:
@@ -442,7 +460,7 @@ class BaseAlgorithm(ABC):
             # the request is parked and carried by the backward pass inside one of its own launches
             self._train_metrics(tb, batch, scores, self.WEIGHTED_METRICS, deferred=self.ride_metrics)
             # single GPU: the gradient is final after the backward pass, so its norm partials come out of it
-            tb['sumsq_valid'] = self.fused_tail and self.world == 1
+            tb['sumsq_valid'] = self.fused_tail and not self._dp_plan()
             self.model.backward(tb['d_scores'], tb['grads'], tb['sumsq'] if tb['sumsq_valid'] else None)
             if self.ride_metrics:
                 _lib.check(_lib.lib().ultr_metrics_flush(_lib.current_stream()), 'ultr_metrics_flush')  # no-op if carried
@@ -454,6 +472,7 @@ class BaseAlgorithm(ABC):
     def step_apply(self):
         """EM state, clip + Adagrad, publish; -> (loss, None, summary)."""
         tb, batch = self._pending
+        self.pending_ctx.bind()
         self._tail = self._arm_tail(tb)                        # consumed by the (last) clip + optimiser call of _update
         self._update(tb, batch)                                # EM state, clip + Adagrad
         _lib.check(_lib.lib().ultr_metrics_tail_flush(_lib.current_stream()), 'ultr_metrics_tail_flush')  # no-op if carried
@@ -482,6 +501,7 @@ class BaseAlgorithm(ABC):
     # ---- evaluation step (shared by every algorithm; dla.py:103-115,329-341) -------------------------
     def _eval_step(self, input_feed):
         Lx = self.max_candidate_num
+        self.pending_ctx.bind()
         batch = self._to_device_batch(input_feed, Lx)
         B = batch.B
         eb = self._eval_bufs.get(B)
@@ -557,7 +577,7 @@ class BaseAlgorithm(ABC):
                 self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
                 _lib.ptr(ths), _lib.ptr(acs), _lib.ptr(grs), int(ns or 0), _lib.ptr(dens), float(scs), float(l2s), float(clips),
                 float(lrs), _lib.ptr(outs),
-                _lib.ptr(sumsq), int(sumsq.numel()) if sumsq is not None else 0, int(tail['n_covered']),
+                _lib.ptr(sumsq), int(sumsq.numel()) if sumsq is not None else (-1 if tail.get('grid_norm') else 0), int(tail['n_covered']),
                 _lib.ptr(pub[0]) if pub else None, ctypes.c_void_p(pub[1]) if pub else None, int(pub[2]) if pub else 0,
                 _lib.current_stream()), 'ultr_clip_adagrad_fused')
             self.model.mark_wt_fresh(ws)
@@ -571,7 +591,7 @@ class BaseAlgorithm(ABC):
             self.strategy, _lib.ptr(out), _lib.ptr(self.opt_ws),
             _lib.ptr(ths), _lib.ptr(acs), _lib.ptr(grs), int(ns or 0), _lib.ptr(dens), float(scs), float(l2s), float(clips),
             float(lrs), _lib.ptr(outs),
-            _lib.ptr(sumsq), int(sumsq.numel()) if sumsq is not None else 0, int(tail['n_covered']),
+            _lib.ptr(sumsq), int(sumsq.numel()) if sumsq is not None else (-1 if tail.get('grid_norm') else 0), int(tail['n_covered']),
             _lib.ptr(pub[0]) if pub else None, ctypes.c_void_p(pub[1]) if pub else None, int(pub[2]) if pub else 0,
             _lib.current_stream()), 'ultr_clip_adagrad3')
         if pub:

@@ -69,7 +69,7 @@ def batch_metrics(plan, scores_lb, labels_lb, docids_lb, n_rows, list_weights, o
                   deferred=False, ties=None):
     """scores/labels/docids position-major [L][B] device tensors -> out[plan.n_out] (device, in place).
 
-    deferred=True parks the request: the next ``ultr_dnn_backward`` of this thread carries it inside one of its own
+    deferred=True parks the request: the next ``ultr_dnn_backward`` under the same request context carries it inside one of its own
     launches (``ultr_metrics_deferred``); every tensor passed here must stay alive until then.
     ties=(seed, step, counter tensor | None, slot_base) with u_pred None: the kernel draws the tie-break uniforms itself
     (``ultr_metrics_ties``), fresh ones on every call like sort_by_scores (metric_utils.py:76-81)."""
