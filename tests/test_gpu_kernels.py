@@ -456,7 +456,9 @@ def test_rem_loss_kernel_many_lists(L, B, Ls):
     assert ((yk == 0) | (yk == 1)).all() and (yk >= ck).all()
 
 
-@pytest.mark.parametrize('B,Ls', [(256, 10), (900, 5), (64, 32), (20000, 10), (333, 16)])  # short-list kernel: L <= 16
+# short-list kernel: L <= 16; from 32768 lists of at most 12 on: one lane per list (pd_loss_lists_body)
+@pytest.mark.parametrize('B,Ls', [(256, 10), (900, 5), (64, 32), (20000, 10), (333, 16), (40000, 10), (33001, 12), (32768, 2),
+                                  (40000, 13)])
 def test_pd_loss_kernel(L, B, Ls):
     rng = np.random.RandomState(13)
     scores, clicks = _scores_clicks(rng, B, Ls)

@@ -82,6 +82,10 @@ def main():
         report('rem_loss fwd+bwd', B, 'lists', 12 * Ls * B, timed(lambda: L.check(lib.ultr_loss_rem_fwdbwd(
             L.ptr(scores), L.ptr(c_lb), B, Ls, L.ptr(prop), None, None, 2024, 1, None, 0, L.ptr(d), None, L.ptr(lw),
             L.ptr(rstats), None, L.ptr(ws), st), 'rem')))
+        tpd, tmd = torch.rand(Ls, device=dev) + 0.5, torch.rand(Ls, device=dev) + 0.5
+        pstats = torch.zeros(Ls * Ls + 1, device=dev)
+        report('pd_loss fwd+bwd', B, 'lists', 12 * Ls * B, timed(lambda: L.check(lib.ultr_loss_pd_fwdbwd(
+            L.ptr(scores), L.ptr(c_lb), B, Ls, L.ptr(tpd), L.ptr(tmd), L.ptr(d), L.ptr(pstats), L.ptr(ws), st), 'pd')))
         plan = M.MetricPlan(['mrr', 'ndcg'], [3, 5, 10])
         out = torch.zeros(plan.n_out, device=dev)
         mws = M.metrics_workspace(B, plan, dev)

@@ -801,6 +801,21 @@ extern "C" int ultr_rem_update_propensity(float* propensity, int L, const float*
   return check_launch("rem_update_kernel");
 }
 
+// Many short lists (B >= kDlaListsMinB, L <= kPdListsMaxL): one lane per list, body in loss_body.hpp.
+constexpr int kPdListsMaxL = 12;  // LT * LT pair sums per lane in registers
+template <int LT>
+__global__ void __launch_bounds__(kLossThreads) pd_loss_lists_kernel(PdArgs a) {
+  __shared__ float s_acc[kMaxStat];
+  __shared__ float s_part[4 * kMaxStat];
+  __shared__ float s_t[32 + LT * LT];
+  pd_loss_lists_body<LT>(a, blockIdx.x, gridDim.x, s_acc, s_part, s_t);
+}
+template <int LT>
+static void launch_pd_lists(const PdArgs& a, unsigned nb, hipStream_t st) {
+  if (a.L == LT) hipLaunchKernelGGL(pd_loss_lists_kernel<LT>, dim3(nb), dim3(kLossThreads), 0, st, a);
+  else if constexpr (LT > 2) launch_pd_lists<LT - 1>(a, nb, st);
+}
+
 extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* t_plus,
                                    const float* t_minus, float* d_scores, float* stats, float* ws, void* stream) {
   int rc = loss_args_ok("ultr_loss_pd_fwdbwd", scores, clicks, B, L, ws);
@@ -809,6 +824,15 @@ extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int
   ULTR_REQUIRE(L <= kPdMaxL, ULTR_ELIMIT, "ultr_loss_pd_fwdbwd: L=%d > %d", L, kPdMaxL);
   rc = ultr_loss_flush(stream);  // a parked request nobody carried runs first: launch order is call order
   if (rc) return rc;
+  if (L >= 2 && L <= kPdListsMaxL && B >= kDlaListsMinB && B <= (1 << 30)) {  // very many short lists: one lane per list
+    const unsigned nb = (unsigned)(cdiv(B, kLossThreads) < kDlaListsMaxBlocks ? cdiv(B, kLossThreads) : kDlaListsMaxBlocks);
+    const PdArgs a{scores, clicks, B, L, t_plus, t_minus, d_scores, stats, ws};
+    {
+      ultr::ProfScope prof_("pd_loss_lists_kernel", as_stream(stream));
+      launch_pd_lists<kPdListsMaxL>(a, nb, as_stream(stream));
+    }
+    return check_launch("pd_loss_lists_kernel");
+  }
   if (L <= 16) {
     PendingLoss p{};
     p.kind = ULTR_RIDE_PD; p.nblocks = small_blocks(B);

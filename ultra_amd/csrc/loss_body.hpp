@@ -748,6 +748,100 @@ __device__ __forceinline__ void pd_loss_small_body(const PdArgs& a, unsigned int
   }
 }
 
+
+// Pairwise debiasing for MANY short lists (exactly LT <= 12 ranks): one lane per LIST, as dla_loss_lists_body.  Its LT
+// scores and clicks sit in registers, every unordered pair is visited once (one exponential, one reciprocal and one
+// logarithm serve both orders), the LT * LT pair-loss sums stay in registers over the grid-stride walk and meet once at
+// the end, and 1 / (t+_k t-_j) comes from an LDS table that every lane reads at the same address.  The 16-lane body
+// spends four cross-lane moves per pair and one group of 16 lanes per list; this one issues nothing but arithmetic.
+// Same pair arithmetic as pd_lane (hardware exp / rcp / log), the per-rank sums in the same rank order; the division by
+// t+ t- is a multiplication by the table's reciprocal, so results agree with pd_lane to rounding, not to the bit.
+template <int LT>
+__device__ __forceinline__ void pd_loss_lists_body(const PdArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
+                                                   float* s_part, float* s_t /* [32 + LT * LT] */) {
+#pragma clang fp contract(off)
+  const int B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float* s_tp = s_t;
+  float* s_tm = s_t + 16;
+  float* s_w = s_t + 32;  // [k][j] = 1 / (t+_k * t-_j)
+  if (tid < 16) {
+    s_tp[tid] = tid < LT ? a.t_plus[tid] : 1.f;
+    s_tm[tid] = tid < LT ? a.t_minus[tid] : 1.f;
+  }
+  __syncthreads();
+  if (tid < LT * LT) s_w[tid] = 1.f / (s_tp[tid / LT] * s_tm[tid % LT]);
+  __syncthreads();
+  float pl[LT][LT];  // l_kj summed over this lane's lists
+#pragma unroll
+  for (int k = 0; k < LT; ++k)
+#pragma unroll
+    for (int j = 0; j < LT; ++j) pl[k][j] = 0.f;
+  auto at = [](const float* row, unsigned int off) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + off); };
+  auto at_w = [](float* row, unsigned int off) { return reinterpret_cast<float*>(reinterpret_cast<char*>(row) + off); };
+#pragma unroll 1
+  for (unsigned int b = bid * kLossThreads + tid; b < (unsigned int)B; b += nb * kLossThreads) {
+    const unsigned int off = b * 4u;
+    float o[LT], c[LT], acc[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      o[l] = *at(a.scores + (long long)l * B, off);
+      c[l] = *at(a.clicks + (long long)l * B, off);
+      acc[l] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < LT; ++k)
+#pragma unroll
+      for (int j = k + 1; j < LT; ++j) {
+        // At most one order of the pair counts: (k, j) when c_k > c_j, (j, k) when c_j > c_k, with weight
+        // m = min(1, |c_k - c_j|) (:147-150).  With x = the counting order's score difference (loser - winner),
+        // its loss is m softplus(x) (:151-155) and d loss / d score is -+ m sigmoid(x) / (t+_winner t-_loser): what the
+        // winner's gradient loses the loser's gains (pd_lane's 1 - sigmoid(-x) is sigmoid(x)).
+        const float d = c[k] - c[j];
+        const float m = fminf(1.f, fabsf(d));   // 0 for a pair that does not count: its terms vanish below
+        const bool kwins = d > 0.f;
+        const float diff = o[j] - o[k];
+        const float x = kwins ? diff : -diff;
+        const float ex = fast_exp(-fabsf(diff));
+        const float inv = fast_rcp(1.f + ex);
+        // log(1 + e), 1 + e in (1, 2]: the bare hardware log2 (1 ulp), no denormal scaling, no correction terms
+        const float lg = __builtin_amdgcn_logf(1.f + ex) * 0.6931471805599453f;
+        const float sg = x >= 0.f ? inv : ex * inv;                 // sigmoid(x)
+        const float val = m * (fmaxf(x, 0.f) + lg);
+        // (both table entries are read, at compile-time addresses: a read at a selected address made the compiler wrap
+        // the rest of the pair in a branch -- "skip when no lane's pair counts", which never happens with 64 lists in
+        // a wave -- and 45 branches cut the loop body into blocks of one dependent chain each, 13 cycles per instruction)
+        const float wkj = s_w[k * LT + j], wjk = s_w[j * LT + k];
+        const float t = m * (kwins ? wkj : wjk) * sg;
+        pl[k][j] += kwins ? val : 0.f;
+        pl[j][k] += kwins ? 0.f : val;
+        acc[k] += kwins ? -t : t;
+        acc[j] += kwins ? t : -t;
+      }
+#pragma unroll
+    for (int l = 0; l < LT; ++l) *at_w(a.d_scores + (long long)l * B, off) = acc[l];
+  }
+  float* mine = s_part + wid * kMaxStat;
+#pragma unroll
+  for (int k = 0; k < LT; ++k)
+#pragma unroll
+    for (int j = 0; j < LT; ++j) {
+      const float v = k == j ? 0.f : wave_sum(pl[k][j]);
+      if (lane == 0) mine[k * LT + j] = v;
+    }
+  if (lane == 0) mine[LT * LT] = 0.f;
+  BlockStats bs{s_part};
+  bs.combine(s_acc, LT * LT + 1, 1 << 30);
+  if (finish_stats(s_acc, LT * LT + 1, 1 << 30, a.ws, a.stats, bid, nb)) {  // block-uniform
+    // loss = sum_ij l_ij / t+_i / t-_j  (:158-159), pre-update ratios: one term per thread, then a block sum
+    __shared__ float red[4];
+    float term[1] = {0.f};
+    if (tid < LT * LT && tid / LT != tid % LT) term[0] = s_acc[tid] / s_tp[tid / LT] / s_tm[tid % LT];
+    block_sum<1>(term, red);
+    if (tid == 0) a.stats[LT * LT] = term[0];
+  }
+}
+
 // A loss request parked by ultr_loss_{dla,ipw,rem,pd}_deferred until the next ultr_dnn_backward under the same request context
 // carries it in its first launch.
 enum { ULTR_RIDE_NONE = 0, ULTR_RIDE_DLA = 1, ULTR_RIDE_IPW = 2, ULTR_RIDE_REM = 3, ULTR_RIDE_PD = 4 };
