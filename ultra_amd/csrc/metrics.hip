@@ -203,17 +203,23 @@ __global__ void __launch_bounds__(kMetThreads) metrics_kernel(MetricsArgs a) {
 // lists of the position-major arrays (fully coalesced, where the group-per-list mapping above touches 16 bytes of each
 // 128-byte line per load), a list's scores / labels / uniforms live in registers, and the positions come from
 // rank-by-counting over the list's pairs -- no lane ever talks to another before the final sums.
-constexpr int kLanesMinB = 32768, kLanesMaxBlocks = 2048;
+constexpr int kLanesMinB = 32768, kLanesMaxBlocks = 1024;  // (four waves per SIMD; every workgroup arrives at ONE counter: ~16 ns each)
 // HAS_U: tie-break uniforms exist (supplied or drawn); without them ties fall to the lower index and no uniform is held.
 template <int LM, bool WANT_ERR, bool HAS_U>
 __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs a) {
   __shared__ float s_vals[4 * kMaxOut];
-  __shared__ float s_log[LM];  // log(rank + 2), the discount's denominator: one table instead of 2 Lx logarithms a list
-  if (threadIdx.x < LM) s_log[threadIdx.x] = logf((float)threadIdx.x + 2.f);
+  // 1 / log(rank + 2), the discount, and 1 / (rank + 1): two tables instead of 2 Lx logarithms and 3 Lx divisions a list
+  // (the discount becomes a multiplication by the correctly rounded reciprocal: 1 ulp from the quotient)
+  __shared__ float s_rlog[LM], s_rinv[LM];
+  if (threadIdx.x < LM) {
+    s_rlog[threadIdx.x] = 1.f / logf((float)threadIdx.x + 2.f);
+    s_rinv[threadIdx.x] = 1.f / (float)(threadIdx.x + 1);
+  }
   const float* __restrict__ scores = a.scores; const float* __restrict__ labels = a.labels;
   const int* __restrict__ docids = a.docids; const float* __restrict__ list_weights = a.list_weights;
   const float* __restrict__ u_pred = a.u_pred;
-  const int n_rows = a.n_rows, B = a.B, Lx = a.Lx, n_topn = a.n_topn, metric_mask = a.metric_mask;
+  const int n_rows = a.n_rows, B = a.B, n_topn = a.n_topn, metric_mask = a.metric_mask;
+  const int Lx = LM == 10 ? 10 : a.Lx;  // (LM == 10 is launched for lists of exactly 10: no per-rank guards survive)
   const int topn[kMaxTopn] = {a.topn[0], a.topn[1], a.topn[2], a.topn[3], a.topn[4], a.topn[5], a.topn[6], a.topn[7]};
   const bool want_mrr = (metric_mask & ULTR_METRIC_MRR) != 0, want_ndcg = (metric_mask & ULTR_METRIC_NDCG) != 0;
   constexpr bool want_err = WANT_ERR;
@@ -221,29 +227,43 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
   const int nout = n_met * n_topn * 2;
   const float inv_pow = 1.f / powf(2.f, a.max_label);
   const int tid = threadIdx.x;
-  // the wave's row of partial sums lives in LDS (only the wave's first lane touches it): 48 accumulators per lane would
-  // cost the kernel an occupancy step
   const bool draw_ties = !u_pred && a.tie_seed != 0ull;
   const unsigned int t_step = draw_ties ? tie_step_of(a) : 0u;
-  float* my_row = s_vals + (tid >> 6) * nout;
-  if ((tid & 63) < nout) my_row[tid & 63] = 0.f;
+  // Per-lane sums over the lane's lists, [metric][topn][plain, weighted] at compile-time positions (only the selected
+  // metrics' first n_topn entries are ever touched); the lanes meet once, after the walk.
+  float acc_m[kMaxTopn][2], acc_n[kMaxTopn][2], acc_e[kMaxTopn][2];
+#pragma unroll
+  for (int q = 0; q < kMaxTopn; ++q) acc_m[q][0] = acc_m[q][1] = acc_n[q][0] = acc_n[q][1] = acc_e[q][0] = acc_e[q][1] = 0.f;
   __syncthreads();
   for (long long b0 = (long long)blockIdx.x * kMetThreads; b0 < B; b0 += (long long)gridDim.x * kMetThreads) {
     const bool on = b0 + tid < B;
     const long long b = on ? b0 + tid : B - 1;  // idle lanes redo the last list and contribute nothing
     float s[LM], lab[LM], u[LM];
+    // every load of the list in one batch (a per-rank "is there a doc id array" test between them made each rank's
+    // loads a basic block of its own, one memory round trip after the other)
 #pragma unroll
     for (int l = 0; l < LM; ++l) {
       s[l] = -INFINITY; lab[l] = 0.f; u[l] = 0.f;
       if (l < Lx) {
         const long long g = (long long)l * B + b;
         s[l] = scores[g];
-        if (docids && docids[g] == n_rows) s[l] = kPaddingScore;
         lab[l] = labels[g];
-        if (HAS_U) u[l] = u_pred ? u_pred[b * Lx + l] : tie_uniform(a, t_step, b, l);
       }
     }
     const float w = list_weights ? list_weights[b] : 1.f;
+    if (docids) {
+      int di[LM];
+#pragma unroll
+      for (int l = 0; l < LM; ++l) di[l] = l < Lx ? docids[(long long)l * B + b] : 0;
+#pragma unroll
+      for (int l = 0; l < LM; ++l)
+        if (l < Lx) s[l] = di[l] == n_rows ? kPaddingScore : s[l];
+    }
+    if (HAS_U) {
+#pragma unroll
+      for (int l = 0; l < LM; ++l)
+        if (l < Lx) u[l] = u_pred ? u_pred[b * Lx + l] : tie_uniform(a, t_step, b, l);
+    }
     // _prepare_and_validate_params: invalid labels (< 0) -> label 0, prediction -> rowmin - 1e-6
     bool any_invalid = false;
     float mn = INFINITY;
@@ -261,27 +281,29 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
           s[l] = mn - 1e-6f;
         }
     }
-    // positions by counting over the pairs j < i: j goes first iff it wins (score desc, uniform asc, index asc)
-    int rank[LM], irank[LM];
-    float above[LM], omr[LM];
+    // Positions by counting over the pairs j < i: j goes first iff it wins (score desc, uniform asc, index asc).  Both
+    // counters of a pair step on the SAME mask (one add-with-carry each): before[i] counts the j < i that go before i,
+    // after[j] the i > j that go after j, and rank = before + (the ranks above) - after.
+    int before[LM], after[LM], ibefore[LM], iafter[LM];
+    float above[LM], omr[LM], gain[LM];
 #pragma unroll
     for (int l = 0; l < LM; ++l) {
-      rank[l] = 0; irank[l] = 0; above[l] = 1.f;
-      omr[l] = 1.f - (exp2f(lab[l]) - 1.f) * inv_pow;
+      before[l] = after[l] = ibefore[l] = iafter[l] = 0;
+      above[l] = 1.f;
+      gain[l] = __builtin_amdgcn_exp2f(lab[l]) - 1.f;  // (labels are small and non-negative: the bare v_exp_f32)
+      omr[l] = 1.f - gain[l] * inv_pow;
     }
 #pragma unroll
     for (int i = 1; i < LM; ++i) {
       if (i < Lx) {
 #pragma unroll
         for (int j = 0; j < i; ++j) {
-          const bool jb = s[j] > s[i] || (s[j] == s[i] && (!HAS_U || u[j] <= u[i]));
-          rank[i] += jb ? 1 : 0;
-          rank[j] += jb ? 0 : 1;
-          if (want_ndcg) {
-            const bool jl = lab[j] >= lab[i];
-            irank[i] += jl ? 1 : 0;
-            irank[j] += jl ? 0 : 1;
-          }
+          const bool jb = HAS_U ? (s[j] > s[i] || (s[j] == s[i] && u[j] <= u[i])) : s[j] >= s[i];
+          before[i] += jb ? 1 : 0;
+          after[j] += jb ? 1 : 0;
+          const bool jl = lab[j] >= lab[i];  // (the ideal order too, wanted or not: a uniform test per pair costs more)
+          ibefore[i] += jl ? 1 : 0;
+          iafter[j] += jl ? 1 : 0;
           if (want_err) {
             above[i] *= jb ? omr[j] : 1.f;
             above[j] *= jb ? 1.f : omr[i];
@@ -292,61 +314,81 @@ __global__ void __launch_bounds__(kMetThreads) metrics_lanes_kernel(MetricsArgs 
       // ~100 lane masks they produce spill from the scalar registers (measured: 2500 readlane / writelane per list walk)
       __builtin_amdgcn_sched_barrier(0);
     }
-    float mrr = 0.f, rel_sum = 0.f, dcg[kMaxTopn], idcg[kMaxTopn], err[kMaxTopn];
-#pragma unroll
-    for (int q = 0; q < kMaxTopn; ++q) dcg[q] = idcg[q] = err[q] = 0.f;
+    float mrr = 0.f, rel_sum = 0.f;
+    int rank[LM], irank[LM];
+    float gd[LM], igd[LM], e_term[LM];
 #pragma unroll
     for (int l = 0; l < LM; ++l) {
+      rank[l] = irank[l] = LM;  // beyond every cutoff
+      gd[l] = igd[l] = e_term[l] = 0.f;
       if (l < Lx) {
-        const float gain = exp2f(lab[l]) - 1.f;
-        rel_sum += gain;
-        if (lab[l] >= 1.f) mrr = fmaxf(mrr, 1.f / (float)(rank[l] + 1));
-        const float gd = gain / s_log[rank[l]], igd = gain / s_log[irank[l]];
+        rank[l] = before[l] + (Lx - 1 - l) - after[l];
+        irank[l] = ibefore[l] + (Lx - 1 - l) - iafter[l];
+        rel_sum += gain[l];
+        // (table reads at unconditional places: a read under a lane condition becomes a branch with its own wait)
+        const float rinv = s_rinv[rank[l]];
+        mrr = fmaxf(mrr, lab[l] >= 1.f ? rinv : 0.f);
+        gd[l] = gain[l] * s_rlog[rank[l]];
+        igd[l] = gain[l] * s_rlog[irank[l]];
         // cumprod(1 - rel) / (1 - rel) as the reference writes it (metrics.py:312-314)
-        const float e_term = want_err ? (1.f - omr[l]) * ((above[l] * omr[l]) / omr[l]) / (float)(rank[l] + 1) : 0.f;
-#pragma unroll
-        for (int q = 0; q < kMaxTopn; ++q)
-          if (q < n_topn) {
-            if (want_ndcg) {
-              dcg[q] += rank[l] < topn[q] ? gd : 0.f;
-              idcg[q] += irank[l] < topn[q] ? igd : 0.f;
-            }
-            if (want_err) err[q] += rank[l] < topn[q] ? e_term : 0.f;
-          }
+        if (want_err) e_term[l] = (1.f - omr[l]) * ((above[l] * omr[l]) / omr[l]) * rinv;
       }
     }
     const float plw_plain = rel_sum != 0.f ? 1.f : 0.f, plw_w = rel_sum != 0.f ? w : 0.f;
-    // outputs in the order [metric][topn][plain, weighted]: the slot index is a running (uniform) count, the per-topn
-    // sums are indexed statically
-    int o = 0;
-    auto emit = [&](float plain, float weighted) {
-      const float v0 = wave_sum(on ? plain : 0.f), v1 = wave_sum(on ? weighted : 0.f);
-      if ((tid & 63) == 0) {
-        my_row[o] += v0;
-        my_row[o + 1] += v1;
-      }
-      o += 2;
-    };
-    if (want_mrr) {
+    const float keep = on ? 1.f : 0.f;
 #pragma unroll
-      for (int q = 0; q < kMaxTopn; ++q)
-        if (q < n_topn) emit(mrr, mrr * w);
-    }
-    if (want_ndcg) {
-#pragma unroll
-      for (int q = 0; q < kMaxTopn; ++q)
-        if (q < n_topn) {
-          const float d = dcg[q], idn = idcg[q];
-          const float nd = idn != 0.f ? d / idn : 0.f;
-          const float ndw = (w * idn) != 0.f ? (w * d) / (w * idn) : 0.f;
-          emit(nd * plw_plain, ndw * plw_w);
+    for (int q = 0; q < kMaxTopn; ++q)
+      if (q < n_topn) {  // uniform
+        if (want_mrr) {
+          acc_m[q][0] += keep * mrr;
+          acc_m[q][1] += keep * (mrr * w);
         }
-    }
-    if (want_err) {
+        if (want_ndcg) {
+          float d = 0.f, idn = 0.f;
 #pragma unroll
-      for (int q = 0; q < kMaxTopn; ++q)
-        if (q < n_topn) emit(err[q], err[q] * w);
+          for (int l = 0; l < LM; ++l) {
+            d += rank[l] < topn[q] ? gd[l] : 0.f;
+            idn += irank[l] < topn[q] ? igd[l] : 0.f;
+          }
+          const float nd = idn != 0.f ? __fdividef(d, idn) : 0.f;
+          const float ndw = (w * idn) != 0.f ? __fdividef(w * d, w * idn) : 0.f;
+          acc_n[q][0] += keep * (nd * plw_plain);
+          acc_n[q][1] += keep * (ndw * plw_w);
+        }
+        if (want_err) {
+          float e = 0.f;
+#pragma unroll
+          for (int l = 0; l < LM; ++l) e += rank[l] < topn[q] ? e_term[l] : 0.f;
+          acc_e[q][0] += keep * e;
+          acc_e[q][1] += keep * (e * w);
+        }
+      }
+  }
+  // outputs in the order [metric][topn][plain, weighted]: the slot index is a running (uniform) count
+  float* my_row = s_vals + (tid >> 6) * nout;
+  int o = 0;
+  auto emit = [&](float plain, float weighted) {
+    const float v0 = wave_sum(plain), v1 = wave_sum(weighted);
+    if ((tid & 63) == 0) {
+      my_row[o] = v0;
+      my_row[o + 1] = v1;
     }
+    o += 2;
+  };
+  if (want_mrr) {
+#pragma unroll
+    for (int q = 0; q < kMaxTopn; ++q)
+      if (q < n_topn) emit(acc_m[q][0], acc_m[q][1]);
+  }
+  if (want_ndcg) {
+#pragma unroll
+    for (int q = 0; q < kMaxTopn; ++q)
+      if (q < n_topn) emit(acc_n[q][0], acc_n[q][1]);
+  }
+  if (want_err) {
+#pragma unroll
+    for (int q = 0; q < kMaxTopn; ++q)
+      if (q < n_topn) emit(acc_e[q][0], acc_e[q][1]);
   }
   __syncthreads();
   metrics_finish(a, blockIdx.x, gridDim.x, s_vals, kMetThreads / 64);
