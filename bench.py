@@ -69,17 +69,47 @@ def kernel_flops_per_launch(name, M):
     return None
 
 
-def measured_traffic(kernel):
-    """HBM-side bytes per launch from the committed PMC passes (tools/collect_profiles.sh, tools/make_traffic.py)."""
-    files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_traffic.json')) \
-        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+def traffic_table(args):
+    """Per-kernel HBM-side bytes per launch from the newest committed PMC passes of THIS workload
+    (tools/collect_profiles.sh, tools/make_traffic.py): profiles/rNN_traffic.json is the default command's,
+    rNN_b4096_traffic.json the mslr30k / 4096-list one, rNN_bf16_traffic.json the default shape in bf16."""
+    pdir = os.path.join(ROOT, 'profiles')
+    if not os.path.isdir(pdir):
+        return None
+    if args.config == 'mslr10k' and args.batch == 256:
+        infix = '_bf16' if args.dtype == 'bf16' else ''
+    elif args.config == 'mslr30k' and args.batch == 4096 and args.dtype != 'bf16':
+        infix = '_b4096'
+    else:
+        return None
+    import re
+    files = sorted(f for f in os.listdir(pdir) if re.fullmatch(r'r\d+%s_traffic\.json' % infix, f))
     if not files:
         return None
-    kernels = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))['kernels']
-    for name, ent in kernels.items():  # template instances are listed as 'name<args>'
+    return json.load(open(os.path.join(pdir, files[-1])))['kernels']
+
+
+def measured_traffic(table, kernel):
+    if not table:
+        return None
+    for name, ent in table.items():  # template instances are listed as 'name<args>'
         if name == kernel or name.startswith(kernel + '<'):
             return ent['hbm_bytes']
     return None
+
+
+def step_traffic(table, kernels, nprof):
+    """HBM-side bytes of one step: every profiled launch of the step priced at its kernel's measured bytes per launch
+    (None if a kernel of the step is missing from the table)."""
+    if not table:
+        return None
+    total = 0.0
+    for name, (cnt, _) in kernels.items():
+        t = measured_traffic(table, name.split('/')[0])
+        if t is None:
+            return None
+        total += t * cnt / float(nprof)
+    return int(total)
 
 
 def build_world(cfg, args, device):
@@ -415,7 +445,7 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS if kname.endswith('_bf16') else PEAK_FP32_MFMA_TFLOPS
             roofline = {'kernel': kname, 'gemm': name.split('/')[1] + (' (sum of K N over the hidden layers)' if '/P' in name else ''), 'bound': 'mfma', 'achieved': round(achieved, 3),
                         'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / peak, 4), 'traffic': measured_traffic(kname),
+                        'frac': round(achieved / peak, 4), 'traffic': measured_traffic(traffic_table(args), kname),
                         'launch_us': round(1e3 * ms, 3), 'flops_per_launch': fl}
     step_gflop = train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9
     if roofline:
@@ -423,6 +453,7 @@ def main():
         # (always against the fp32 matrix peak: the weight gradients -- a third of the flops -- run fp32 MFMA in both modes)
         roofline['step_frac'] = round(step_gflop / (1e3 * dt / args.steps) / PEAK_FP32_MFMA_TFLOPS, 4)  # GFLOP / ms = TFLOP/s
         roofline['launches_per_step'] = round(sum(c for c, _ in kernels.values()) / float(nprof), 2)
+        roofline['step_traffic_bytes'] = step_traffic(traffic_table(args), kernels, nprof)
 
     out = {
         'metric': 'train query-lists/sec (DNN+DLA, MSLR-10K shape)' if args.config == 'mslr10k'
