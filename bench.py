@@ -409,6 +409,14 @@ def main():
     loss_value = float(last[0])
     lists = args.steps * args.batch * world
     value = lists / dt
+    # several ranks: every replica must hold the same parameters after the timed steps (one bucket applied to the same
+    # variables on every rank) -- a captured collective that did not do its job would show here
+    replicas_equal = None
+    if world > 1:
+        chk = torch.stack([model.model.params.double().sum(), model.model.params.double().abs().sum()])
+        got = [torch.zeros_like(chk) for _ in range(world)]
+        torch.distributed.all_gather(got, chk)
+        replicas_equal = all(bool(torch.equal(g, got[0])) for g in got)
 
     # ---- per-kernel durations with HIP events on the launch stream (same workload, eager launches)
     roofline, kernels = None, {}
@@ -467,6 +475,7 @@ def main():
                                    'PBM' if 'pbm' in cfg['click'] else 'cascade', cfg['Q'], 'toy-data' if cfg.get('data_dir') else 'synthetic'),
                    'global_batch': args.batch * world, 'list_size': cfg['L'], 'parallelism': 'dp%d' % world,
                    'launch': launch, 'steps_per_graph': spc, 'feed_prefetch': bool(args.prefetch),
+                   'replicas_equal': replicas_equal,
                    'train_gflop_per_step_per_gpu': round(train_flops_per_list(cfg['F'], cfg['L']) * args.batch / 1e9, 3)},
         'final_loss': loss_value,
     }
