@@ -281,7 +281,7 @@ int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const 
  *   The chain kernel evaluates d_score with the loss kernels' own lane functions (same bits) and writes scores and the
  *   list weights; the request's statistics (and d_scores, prop_grads, pw_out) are produced by rider workgroups of the
  *   slab-reduction launch (the third of the step's launches).  A parked ultr_metrics_deferred request rides there too
- *   (lists of 9 to 16, at most 1024 lists; otherwise it gets a launch of its own), a parked
+ *   (lists of 9 to 16, at most 8192 lists; otherwise it gets a launch of its own), a parked
  *   ultr_batch_assemble_deferred request with the update launch (ultr_clip_adagrad_fused).
  *   Two row tiles: 16 rows per workgroup while the batch is at most one workgroup per CU (256 workgroups), 32 rows
  *   (chain32.hpp: the reference's default scorer -- elu, layer normalisation, hidden widths multiples of 16 -- in

@@ -1944,7 +1944,7 @@ extern "C" int ultr_dnn_backward(const UltrDnnDesc* desc, const float* params, c
 extern "C" int ultr_dnn_sumsq_count(const UltrDnnDesc* desc) {
   if (ultr_check_desc(desc, "ultr_dnn_sumsq_count") != ULTR_OK) return -1;
   const Layout L = make_layout(desc, 1);
-  int n = (3 * L.K[L.H] + 1 + 63) / 64;
+  int n = (3 * L.K[L.H] + 1 + kFinOutCols - 1) / kFinOutCols;
   for (int j = 0; j < L.H; ++j) n += L.K[j];
   return n;
 }
@@ -2237,7 +2237,7 @@ static int dnn_backward_impl(const UltrDnnDesc* desc, const float* params, const
   f.params = params; f.grads = grads; f.has_ln = has_ln || bn;
   f.outpart = ws + L.outpart; f.out_blocks = bn ? 1 : L.out_blocks; f.Kout = L.K[H];
   f.sumsq = sumsq;
-  const unsigned fblocks = (unsigned)(start + (3 * L.K[H] + 1 + 63) / 64);
+  const unsigned fblocks = (unsigned)(start + (3 * L.K[H] + 1 + kFinOutCols - 1) / kFinOutCols);
   if (g_pending_assemble.on && g_pending_assemble.nblocks <= 4096) {
     FinalizeRiderArgs fr{};
     fr.f = f; fr.a = g_pending_assemble.a;

@@ -151,6 +151,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, int bx, int by, i
 //   dgamma_k = sum_n W[k][n] G[k][n] ; dbeta_k = sum_n W[k][n] S[n]
 // one block per (hidden layer, input row k); the last block reduces the output-layer partials
 // ---------------------------------------------------------------------------------------------
+// columns of the output layer's partial rows one slab-reduction workgroup takes (finalize_body); its other 256 / 16
+// thread groups split the rows
+constexpr int kFinOutCols = 16;
 struct FinalizeArgs {
   int H;
   int row_start[ULTR_MAX_LAYERS + 1];  // block index ranges per layer
@@ -168,31 +171,36 @@ struct FinalizeArgs {
 __device__ __forceinline__ void finalize_body(const FinalizeArgs& p, const int blk) {
   __shared__ float red[12];
   if (blk >= p.row_start[p.H]) {  // output layer: column sums of the [out_blocks][3K+4] partial rows
-    __shared__ float s_col[4][64];
+    // A workgroup takes 16 columns and splits the partial rows over its 16 thread groups (64 columns x 4 groups until
+    // round 3: at 4096 lists -- 1366 rows, 341 per thread -- that made these workgroups the launch's pole, 21 us against 8)
+    __shared__ float s_col[kThreads];
     const int K = p.Kout, j = p.H;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = (blk - p.row_start[p.H]) * 64 + c;
+    constexpr int cols = kFinOutCols;
+    const int ng = (int)blockDim.x / cols;
+    const int c = threadIdx.x % cols, g = threadIdx.x / cols;
+    const int i = (blk - p.row_start[p.H]) * cols + c;
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < 3 * K + 1) {
       int b = g;
-      for (; b + 60 < p.out_blocks; b += 64) {  // 16 independent loads in flight per thread (one round trip each round)
+      for (; b + 15 * ng < p.out_blocks; b += 16 * ng) {  // 16 independent loads in flight per thread (one round trip each round)
         float v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = p.outpart[(long long)(b + 4 * q) * (3 * K + 4) + i];
+        for (int q = 0; q < 16; ++q) v[q] = p.outpart[(long long)(b + ng * q) * (3 * K + 4) + i];
 #pragma unroll
         for (int q = 0; q < 16; ++q) a4[q & 3] += v[q];
       }
-      for (; b + 12 < p.out_blocks; b += 16) {  // 4 independent loads in flight per thread
+      for (; b + 3 * ng < p.out_blocks; b += 4 * ng) {  // 4 independent loads in flight per thread
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a4[q] += p.outpart[(long long)(b + 4 * q) * (3 * K + 4) + i];
+        for (int q = 0; q < 4; ++q) a4[q] += p.outpart[(long long)(b + ng * q) * (3 * K + 4) + i];
       }
-      for (; b < p.out_blocks; b += 4) a4[0] += p.outpart[(long long)b * (3 * K + 4) + i];
+      for (; b < p.out_blocks; b += ng) a4[0] += p.outpart[(long long)b * (3 * K + 4) + i];
     }
-    s_col[g][c] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    s_col[g * cols + c] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     __syncthreads();
     float q[1] = {0.f};
     if (g == 0 && i < 3 * K + 1) {
-      const float sum = (s_col[0][c] + s_col[1][c]) + (s_col[2][c] + s_col[3][c]);
+      float sum = 0.f;
+      for (int gg = 0; gg < ng; ++gg) sum += s_col[gg * cols + c];
       bool stored = true;
       if (i < K) p.grads[p.off_W[j] + i] = sum;  // W_out is a plain [K] vector
       else if (i < 2 * K) { if (p.has_ln) p.grads[p.off_gamma[j] + (i - K)] = sum; else stored = false; }

@@ -1605,9 +1605,11 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   f.params = params; f.grads = grads; f.has_ln = has_ln;
   f.outpart = ws + P.outpart; f.out_blocks = P.nwg; f.Kout = P.K[H];
   f.sumsq = sumsq;
-  const unsigned fblocks = (unsigned)(start + (3 * P.K[H] + 1 + 63) / 64);
+  const unsigned fblocks = (unsigned)(start + (3 * P.K[H] + 1 + kFinOutCols - 1) / kFinOutCols);
   // too big to ride along, or lists of at most 8 (the rider is compiled for 16-lane groups): a launch of its own
-  if (g_pending_metrics.on && (g_pending_metrics.nblocks > 64 || g_pending_metrics.a.P != 16)) {
+  // (up to 512 rider workgroups = 8192 lists: beside the ~900 of the slab reduction they still fit the chip at once)
+  constexpr unsigned kFusedMaxMetricRiders = 512;
+  if (g_pending_metrics.on && (g_pending_metrics.nblocks > kFusedMaxMetricRiders || g_pending_metrics.a.P != 16)) {
     g_pending_metrics.on = false;
     rc = launch_metrics_now(g_pending_metrics.a, g_pending_metrics.nblocks, st);
     if (rc) return rc;
