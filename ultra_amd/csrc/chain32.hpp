@@ -476,6 +476,12 @@ __global__ void __launch_bounds__(kTcThreads) train_chain32_kernel(TcArgs p) {
     }
   }
 
+  // the transposed weights of the first dgrad GEMM stream in under the output-layer backward stage and the partial-row
+  // reduction
+  if (H >= 2) {
+    g = tc_geo(p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w, false);
+    c32_prefetch(g, l31, h, R);
+  }
   // ---- output-layer backward: dz of the last hidden layer (-> first panel and memory) and the gradient partials
   {
     const int ldz = p.ldn[H - 1];
@@ -548,11 +554,6 @@ __global__ void __launch_bounds__(kTcThreads) train_chain32_kernel(TcArgs p) {
   }
 
   TC_WSTAMP(9);
-  // the transposed weights of the first dgrad GEMM stream in under the partial-row reduction
-  if (H >= 2) {
-    g = tc_geo(p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w, false);
-    c32_prefetch(g, l31, h, R);
-  }
   lds_barrier();
   {
     float* out = p.outpart + (long long)blockIdx.x * (3 * Ko + 4);

@@ -791,6 +791,13 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     }
   }
 
+  // the transposed weights of the first dgrad GEMM stream in under the output-layer backward stage and the partial-row
+  // reduction (requested after them, the first chunk's latency was exposed: 0.7 us)
+  if (H >= 2) {
+    g = tc_geo(BF ? p.WTp[H - 1] : p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w, BF);
+    g.dbg = p.dbg;
+    tc_prefetch<FAST, BF>(g, nn, kk, R);
+  }
   // ---- output-layer backward: dz of the last hidden layer (-> P1 and memory) and the parameter-gradient partials
   {
     const int ldz = p.ldn[H - 1];
@@ -879,13 +886,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
     if (lane == 0) mine[3 * Ko] = go[0] + go[1];
   }
 
-  // the transposed weights of the first dgrad GEMM stream in under the partial-row reduction
   int cur_is_p1 = 1;
-  if (H >= 2) {
-    g = tc_geo(BF ? p.WTp[H - 1] : p.WT[H - 1], p.N[H - 1], p.K[H - 1], (p.K[H - 1] + 3) & ~3, w, BF);
-    g.dbg = p.dbg;
-    tc_prefetch<FAST, BF>(g, nn, kk, R);
-  }
   TC_STAMP(17);
   TC_WSTAMP(9);
   lds_barrier();
