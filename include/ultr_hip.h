@@ -70,6 +70,7 @@ extern "C" {
 #define ULTR_MAX_LIST 64     /* max rank_list_size for the loss / feed kernels   */
 #define ULTR_MAX_SORT 2048   /* max list length for the metric sort              */
 #define ULTR_MAX_WIDTH 1024  /* max hidden width                                 */
+#define ULTR_FEED_INFO_INTS 1088 /* int32 words of the feed kernels' `info` array  */
 
 /* activation_func (base_ranking_model.py:59-65) */
 enum { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1, ULTR_ACT_SELU = 2, ULTR_ACT_TANH = 3, ULTR_ACT_SIGMOID = 4 };
@@ -187,9 +188,10 @@ int ultr_click_sample(int click_model, const float* labels, long long n, int L, 
  *   slot_start.. ; info[0] = candidates consumed, info[1] = slots filled so far.
  * step_ctr (mode 0, may be NULL): device uint32 added to `step` and incremented once per call by
  *   the last workgroup to finish -- kernel arguments are frozen in a hipGraph, this is not.
- * info: int32[36] device, zero-initialised: {consumed, filled, unused, arrival counter, [4..20) 16 partial attempt
- *   counters (mode 0 diagnostic: their sum is the number of attempts made so far; B / attempts = acceptance rate),
- *   [20..36) arrival sub-counters}. */
+ * info: int32[ULTR_FEED_INFO_INTS] device, zero-initialised: {consumed, filled, unused, arrival counter}, then 32
+ *   counters, each on a 128-byte line of its own (atomics on one line serialise at ~16 ns each whatever the word):
+ *   info[64 + 32 k], k < 16: partial attempt counters (mode 0 diagnostic: their sum is the number of attempts made so
+ *   far; B / attempts = acceptance rate); info[64 + 32 (16 + k)], k < 16: arrival sub-counters. */
 int ultr_batch_assemble(const int* initial_list, const float* labels, int Q, int Lmax, int L, int B,
                         int click_model, const double* exam, int n_exam, const double* click_prob,
                         int n_click_prob, int mode, unsigned long long seed, unsigned int step,

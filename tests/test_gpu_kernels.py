@@ -206,7 +206,8 @@ def _assemble(L, data, B, Ls, model, mode, seed=0, step=0, slot_base=0, u=None, 
     if out is None:
         out = (torch.full((Ls, B), -7, dtype=torch.int32, device='cuda'),
                torch.full((Ls, B), -7.0, dtype=torch.float32, device='cuda'),
-               torch.full((B,), -7, dtype=torch.int32, device='cuda'), torch.zeros(36, dtype=torch.int32, device='cuda'))
+               torch.full((B,), -7, dtype=torch.int32, device='cuda'),
+               torch.zeros(L.ULTR_FEED_INFO_INTS, dtype=torch.int32, device='cuda'))
     ud = None if u is None else dev(u, torch.float64)
     n_cand = 0 if u is None else u.shape[0]
     n_rows = data.features.shape[0]
@@ -272,7 +273,7 @@ def test_batch_assemble_philox_slots_bit_exact_and_dp_invariant(L):
     assert idx.cpu().tolist()[:64] == w_idx
     assert np.array_equal(clicks.cpu().numpy().T[:64], np.array(w_clicks, dtype=np.float32))
     assert (clicks.sum(dim=0) > 0).all()
-    assert sum(info.cpu().tolist()[4:20]) == sum(O.get_batch_slots(
+    assert sum(info.cpu().tolist()[64:64 + 32 * 16:32]) == sum(O.get_batch_slots(
         data.initial_list, data.labels, Ls, B, model['model_name'], model['click_prob'], model['exam_prob'], seed, step)[2])  # attempts
     # two "ranks" with B/2 lists each reproduce the one-big-batch run bit for bit
     a = _assemble(L, data, B // 2, Ls, model, 0, seed=seed, step=step, slot_base=0)

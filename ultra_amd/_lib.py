@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libultr_hip.so')
 
 ULTR_MAX_LAYERS = 8
 ULTR_MAX_LIST = 64
+ULTR_FEED_INFO_INTS = 1088
 
 ACT = {'elu': 0, 'relu': 1, 'selu': 2, 'tanh': 3, 'sigmoid': 4}
 NORM_NONE, NORM_LAYER, NORM_BATCH, NORM_BATCH_EVAL = 0, 1, 2, 3

@@ -81,8 +81,9 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
     if (threadIdx.x == 0) {
       const unsigned int cur = __hip_atomic_load(step_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_cur = cur;
-      // two levels (16 sub-counters, then info[3]): a thousand returning atomics on one address take 16 us
-      unsigned int* sub = reinterpret_cast<unsigned int*>(&info[20 + (bid & 15)]);
+      // two levels (16 sub-counters, then info[3]): a thousand returning atomics on one address take 16 us -- and on one
+      // 128-byte LINE: sixteen counters side by side still ran the kernel 20 us at 4096 slots, so each has its own line
+      unsigned int* sub = reinterpret_cast<unsigned int*>(&info[64 + 32 * (16 + (bid & 15))]);
       const unsigned int n_sub = ((unsigned)nb - (unsigned)(bid & 15) + 15u) / 16u;  // blocks that share this sub-counter
       // the arrival must not be issued before the counter value has come back: wait for the load, and keep the
       // compiler from moving either memory operation across this point
@@ -197,7 +198,7 @@ __device__ __forceinline__ void assemble_slots_body(const AssembleArgs& a, int b
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0 && s_attempts) atomicAdd(&info[4 + (bid & 15)], s_attempts);
+  if (threadIdx.x == 0 && s_attempts) atomicAdd(&info[64 + 32 * (bid & 15)], s_attempts);
 }
 
 

@@ -68,7 +68,7 @@ class ClickSimulationFeed(BaseInputFeed):
         self.step_ctr = shared if shared is not None else torch.zeros(1, dtype=torch.int32, device=self.device)
         if hasattr(model, 'step_ctr') and shared is None and self.hparams.device_rng:
             model.step_ctr = self.step_ctr
-        self.info = torch.zeros(36, dtype=torch.int32, device=self.device)
+        self.info = torch.zeros(_lib.ULTR_FEED_INFO_INTS, dtype=torch.int32, device=self.device)
         self._out = {}
         # prefetch: (data set, batch size, check_validation) the buffers were last filled / parked for
         self._prefetched = None
