@@ -255,6 +255,42 @@ __device__ __forceinline__ bool last_block_arrive_sc1(unsigned int* counter, uns
   return s_last_sc1 != 0u;
 }
 
+// The same hand-off for MANY workgroups.  Returning atomics on one address -- or on one 128-byte line -- serialise at
+// ~16 ns each (1024 arrivals: 16 us, most of it in the launch's tail, when the last wave of workgroups finishes together),
+// so from kArriveTwoLevelMin workgroups on the arrival goes through 16 sub-counters, each on a line of its own, whose
+// last arrivers meet at the top counter.  The workspace then keeps its partial rows behind the sub-counters:
+// ws[0] top counter, ws[32 + 32 k] sub-counter k, rows from arrive_rows(ws, nb) -- writers and the reader apply the same
+// rule, and the ultr_*_workspace_floats sizes include the room.  Counters return to zero by themselves.
+constexpr unsigned int kArriveTwoLevelMin = 128;
+constexpr int kArriveRowsFar = 576;  // floats in front of the rows when the arrival has two levels
+__device__ __forceinline__ float* arrive_rows(float* ws, unsigned int nb) {
+  return ws + (nb >= kArriveTwoLevelMin ? kArriveRowsFar : 8);
+}
+__device__ __forceinline__ bool last_block_arrive_ws(float* ws, unsigned int bid, unsigned int nb) {
+  unsigned int* top = reinterpret_cast<unsigned int*>(ws);
+  if (nb < kArriveTwoLevelMin) return last_block_arrive_sc1(top, nb);
+  __shared__ unsigned int s_last_2l;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* sub = top + 32 + 32 * (bid & 15u);
+    const unsigned int n_sub = (nb - (bid & 15u) + 15u) / 16u;  // workgroups that share this sub-counter
+    unsigned int last = 0u;
+    const unsigned int t = __hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == n_sub - 1u) {
+      __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int t2 = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t2 == 15u) {
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1u;
+      }
+    }
+    s_last_2l = last;
+  }
+  __syncthreads();
+  return s_last_2l != 0u;
+}
+
 // ---- Philox4x32-10 -------------------------------------------------------------------------
 struct Philox4 {
   uint32_t w0, w1, w2, w3;

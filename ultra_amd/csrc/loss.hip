@@ -530,7 +530,7 @@ extern "C" long long ultr_loss_workspace_floats(int B, int L) {
   const long long blocks = cdiv(B > 0 ? B : 1, 16);  // the short-list DLA kernel runs 16 lists per block
   long long ns = 4 + 4 * (long long)L;
   if ((long long)L * L + 1 > ns) ns = (long long)L * L + 1;
-  return 8 + blocks * ns;
+  return 8 + blocks * ns + kArriveRowsFar;  // (+ room for the two-level arrival's sub-counters, common.hpp)
 }
 
 static int loss_args_ok(const char* who, const void* scores, const void* clicks, int B, int L, const void* ws) {

@@ -52,11 +52,10 @@ __device__ __forceinline__ bool finish_stats(float* s_acc, int ns, int max_from,
   // before the workgroup barrier that precedes the counter's atomic add, and the last block loads only after its own
   // add has returned.  The fenced form (buffer_wbl2 + buffer_inv) costs 3-4 us here, more while other workgroups of
   // the launch keep the L2 dirty.
-  unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
-  float* rows = ws + 8;
+  float* rows = arrive_rows(ws, nb);
   __syncthreads();
   for (int s = threadIdx.x; s < ns; s += blockDim.x) st_agent(rows + (long long)bid * ns + s, s_acc[s]);
-  const bool last = last_block_arrive_sc1(counter, nb);
+  const bool last = last_block_arrive_ws(ws, bid, nb);
   if (last) {
     __shared__ float s_tmp[kLossThreads];
     if (ns <= (int)blockDim.x) {

@@ -427,7 +427,7 @@ using namespace ultr;
 
 extern "C" long long ultr_metrics_workspace_floats(int B, int n_topn) {
   // worst case: one list per block
-  return 8 + (long long)(B > 0 ? B : 1) * 3 * (n_topn > 0 ? n_topn : 1) * 2;
+  return 8 + (long long)(B > 0 ? B : 1) * 3 * (n_topn > 0 ? n_topn : 1) * 2 + kArriveRowsFar;  // (+ two-level arrival, common.hpp)
 }
 
 namespace ultr {
@@ -591,9 +591,9 @@ extern "C" int ultr_metrics_static(const float* scores, const float* labels, con
   rc = prepare_metrics("ultr_metrics_static", scores, labels, docids, n_rows, list_weights, u_pred, B, Lx, topn_h, n_topn,
                        metric_mask, max_label, out, ws, &a, &nblocks);
   if (rc) return rc;
-  // the array keeps the last call's contents: the arrival counter (first 8 floats) must start at zero even if an
+  // the array keeps the last call's contents: the arrival counters (the first kArriveRowsFar floats) must start at zero even if an
   // earlier launch on this device was torn down half-way; the partial rows are overwritten before they are read
-  const hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), as_stream(stream));
+  const hipError_t e = hipMemsetAsync(ws, 0, kArriveRowsFar * sizeof(float), as_stream(stream));
   ULTR_REQUIRE(e == hipSuccess, ULTR_EHIP, "ultr_metrics_static: hipMemsetAsync: %s", hipGetErrorString(e));
   return launch_metrics_now(a, nblocks, as_stream(stream));
 }

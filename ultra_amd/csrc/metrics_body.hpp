@@ -276,8 +276,7 @@ __device__ __forceinline__ void metrics_finish(const MetricsArgs& a, int bid, in
     for (int l = 0; l < nrow; ++l) s += s_vals[l * nout + tid];
     s_acc[tid] = s;
   }
-  unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
-  float* rows = ws + 8;
+  float* rows = a.defer_reduce ? ws + 8 : arrive_rows(ws, (unsigned int)nb);  // (deferred: no arrival, MetricsTail reads ws + 8)
   __syncthreads();
   if (a.defer_reduce) {  // the next launch on the stream adds the rows
     if (tid < nout) rows[(long long)bid * nout + tid] = s_acc[tid];
@@ -285,7 +284,7 @@ __device__ __forceinline__ void metrics_finish(const MetricsArgs& a, int bid, in
   }
   // hand-off without cache maintenance: agent-scope stores and loads around an atomic arrival counter (loss_body.hpp)
   if (tid < nout) st_agent(rows + (long long)bid * nout + tid, s_acc[tid]);
-  if (last_block_arrive_sc1(counter, nb)) {
+  if (last_block_arrive_ws(ws, (unsigned int)bid, (unsigned int)nb)) {
     __shared__ float s_tmp[kMetThreads];
     reduce_rows<true>(rows, (int)nb, nout, 1 << 30, s_tmp, s_acc);
     if (tid < nout && ((tid & 1) == 0 || list_weights)) out[tid] = s_acc[tid] / (float)B;
