@@ -487,7 +487,7 @@ int ultr_sort_by_scores(const float* scores, const float* u, int B, int Lx, int 
  * if clip_norm > 0: g *= clip_norm / max(norm, clip_norm);
  * Adagrad: acc += g^2; theta -= lr * g / sqrt(acc)  (acc starts at 0.1, no epsilon); SGD:
  * theta -= lr*g.  out_norm (device float, may be NULL) receives the pre-clip norm.
- * ws: at least 1024+8 floats, zero-initialised once. */
+ * ws: at least 2048 floats, zero-initialised once (1024 + 8 without the n_sumsq == -1 option of ultr_clip_adagrad3). */
 int ultr_clip_adagrad(float* theta, float* acc, const float* grads, long long n, const float* denom,
                       float scale_const, float l2, float clip_norm, float lr, int strategy,
                       float* out_norm, float* ws, void* stream);
@@ -509,7 +509,7 @@ int ultr_clip_adagrad2(float* theta, float* acc, const float* grads, long long n
  *     pass over the gradient; the small group then rides with the update launch.
  *   sumsq == NULL and n_sumsq == -1: no partials exist (data parallel: the gradient is final only after the
  *     collective), and the update launch forms the norm ITSELF -- every update workgroup leaves the partial of its own
- *     elements in ws, arrives at a counter (ws[0], which only ever grows: do not clear ws between calls) and waits
+ *     elements in ws, arrives at a counter (two levels: ws[1040 + 32 k] and ws[0], which only ever grow: do not clear ws between calls) and waits
  *     for the launch's other update workgroups (at most 1024, co-resident) -- instead of a norm launch before it.
  *     With sumsq != NULL and l2 != 0 the same happens (the partials describe the raw gradient only).
  *   publish_n > 0: workgroup 0 copies publish_n floats publish_src -> publish_dst, with out_norm / out_norm_s

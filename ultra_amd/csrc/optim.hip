@@ -149,18 +149,32 @@ __global__ void __launch_bounds__(kOptThreads) adagrad_apply_kernel(float* __res
       part[0] += a * a;
     }
     block_sum<1>(part, red);
-    // ... published write-through, then the launch-wide rendezvous: the counter only ever grows (it is never reset, so
-    // a replayed graph needs no memset); the arrivals of one launch share the target (old / nblk + 1) * nblk because a
-    // stream runs its launches in order.  (2^32 arrivals, some 10^7 steps, would wrap it: not handled.)
+    // ... published write-through, then the launch-wide rendezvous.  The counters only ever grow (never reset, so a
+    // replayed graph needs no memset) and a stream runs its launches in order, so the arrivals of one launch share an
+    // epoch: (old value) / (arrivals per launch).  Two levels, because returning atomics on one line serialise at
+    // ~16 ns each (232 arrivals: 3.7 us): 16 sub-counters on lines of their own (ws[1040 + 32 k]), whose last arrivers
+    // of the epoch step the top counter (ws[0], 16 per launch); everybody polls the top counter.  (2^32 arrivals, some
+    // 10^8 steps, would wrap a counter: not handled.)
     float* wsw = const_cast<float*>(ws);
     if (threadIdx.x == 0) {
       st_agent(wsw + 8 + bid, part[0]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned int* ctr = reinterpret_cast<unsigned int*>(wsw);
+      unsigned int* top = reinterpret_cast<unsigned int*>(wsw);
       const unsigned int nb = (unsigned int)nblk;
-      const unsigned int old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int target = (old / nb + 1u) * nb;
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+      if (nb < 32u) {
+        const unsigned int old = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int target = (old / nb + 1u) * nb;
+        while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+      } else {
+        const unsigned int k = bid & 15u;
+        unsigned int* sub = top + 1040 + 32 * k;
+        const unsigned int n_sub = (nb - k + 15u) / 16u;  // update workgroups that share this sub-counter
+        const unsigned int old = __hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int epoch = old / n_sub;
+        if (old % n_sub == n_sub - 1u) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int target = (epoch + 1u) * 16u;
+        while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+      }
     }
     __syncthreads();
     for (int p = threadIdx.x; p < n_partials; p += blockDim.x) ssq[0] += ld_agent(ws + 8 + p);
