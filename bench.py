@@ -63,9 +63,9 @@ def kernel_flops_per_launch(name, M):
     m = re.search(r'/K(\d+)N(\d+)$', name)
     if m:
         return 2.0 * M * int(m.group(1)) * int(m.group(2))
-    m = re.search(r'/P(\d+)$', name)
+    m = re.search(r'/P(\d+)(?:M(\d+))?$', name)   # 'M<rows>': a launch that covers part of the batch
     if m:
-        return 2.0 * M * int(m.group(1))
+        return 2.0 * (int(m.group(2)) if m.group(2) else M) * int(m.group(1))
     return None
 
 

@@ -288,12 +288,17 @@ int ultr_dnn_backward_sumsq(const UltrDnnDesc* desc, const float* params, const 
  *   Two row tiles: 16 rows per workgroup while the batch is at most one workgroup per CU (256 workgroups), 32 rows
  *   (chain32.hpp: the reference's default scorer -- elu, layer normalisation, hidden widths multiples of 16 -- in
  *   fp32, widths up to 768) beyond; ultr_dnn_fused_rows says which one a (desc, B, L) gets (0: not supported).
+ *   A 32-row launch runs in rounds of 256 workgroups (one per CU); when the lists beyond its last full round fit one
+ *   round of 16-row workgroups they run as a second launch of those instead of a last, mostly empty round
+ *   (4096 lists of 10: 1280 x 3 lists, then 256 x 1).  ultr_dnn_fused_tail_lists: how many lists that launch takes (0:
+ *   there is none; -1: bad descriptor).  Which kernel scores a list depends on (B, L) only; the two agree to rounding.
  *   grads[0..n_params) and sumsq (may be NULL) as ultr_dnn_backward_sumsq.  docids [L][B] position-major.
  * ultr_dnn_fused_workspace_bytes: bytes of workspace for (B, L); 0 when the shape is not supported (no hidden layer,
  * L > 16, widths whose 16-row panels do not fit the 160 KB of LDS) -- use the separate entry points then; -1 on a bad
  * descriptor. */
 long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int B, int L);
 int ultr_dnn_fused_rows(const UltrDnnDesc* desc, int B, int L);
+int ultr_dnn_fused_tail_lists(const UltrDnnDesc* desc, int B, int L);
 /* workspace: zero-initialised by the caller before its first use and used for this (desc, B, L) only.
  * wt_fresh != 0: the transposed weight copies the workspace keeps for the dgrad GEMMs are current, i.e. the
  *   parameters have not changed since the last ultr_clip_adagrad_fused call on this workspace; 0: they are rebuilt

@@ -44,7 +44,15 @@ CASES = [
     ('PairDebias', '', 'hidden_layer_sizes=[512, 256, 128]', 220, 10, 301),
     ('IPWrank', 'propensity_estimator_json=%s' % IPW_JSON, 'hidden_layer_sizes=[128, 64]', 40, 8, 520),
     ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 16, 258),
+    # a last round of 32-row workgroups that would be mostly empty: whole rounds of 256 x 32 rows, then the remaining
+    # lists as a launch of 16-row workgroups (TAIL: lists in that launch)
+    ('DLA', '', 'hidden_layer_sizes=[512, 256, 128]', 136, 10, 1000),
+    ('RegressionEM', '', 'hidden_layer_sizes=[128, 64]', 220, 10, 769),
+    ('PairDebias', '', 'hidden_layer_sizes=[256, 128]', 60, 10, 1024),
+    ('IPWrank', 'propensity_estimator_json=%s' % IPW_JSON, 'hidden_layer_sizes=[128, 64]', 40, 8, 1300),
+    ('DLA', '', 'hidden_layer_sizes=[64, 32]', 24, 16, 600),
 ]
+TAIL = {1000: 232, 769: 1, 1024: 256, 1300: 276, 600: 88}
 
 
 @pytest.mark.parametrize('algo,hp,mhp,F,L,B', CASES)
@@ -58,6 +66,7 @@ def test_fused_step_equals_the_per_launch_plan(algo, hp, mhp, F, L, B):
     m2.fused_step = False
     assert m1.model.fused_supported(B, L)
     assert m1.model.fused_rows(B, L) == (32 if B > 256 else 16)
+    assert m1.model.fused_tail_lists(B, L) == TAIL.get(B, 0)
     rng = np.random.RandomState(2)
     for step in range(3):
         feed_dict, _ = feed.get_batch(data, check_validation=True)

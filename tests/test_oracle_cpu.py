@@ -396,7 +396,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     assert lib.ultr_version() == 100
     # argument validation happens before any launch, so it can be exercised without a GPU
-    assert lib.ultr_loss_workspace_floats(256, 10) == 8 + 16 * 101
+    assert lib.ultr_loss_workspace_floats(256, 10) == 8 + 16 * 101 + 576  # + the far rows of the two-level arrival
     assert lib.ultr_click_pbm(None, 1, 1, None, 1, None, 1, None, 0, 0, None, None) == -1
     assert b'null pointer' in lib.ultr_last_error()
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     'ultr_dnn_sumsq_count': (_I, [_DESC]),
     'ultr_dnn_fused_workspace_bytes': (_LL, [_DESC, _I, _I]),
     'ultr_dnn_fused_rows': (_I, [_DESC, _I, _I]),
+    'ultr_dnn_fused_tail_lists': (_I, [_DESC, _I, _I]),
     'ultr_dnn_train_fused': (_I, [_DESC, _P, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     'ultr_clip_adagrad_fused': (_I, [_DESC, _I, _I, _P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _I, _P, _P, _P, _P, _P, _I, _P,
                                      _F, _F, _F, _F, _P, _P, _I, _LL, _P, _P, _I, _P]),

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain32_kernel(TcArgs p) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int L = p.L, B = p.B, nl = p.nl, H = p.H;
-  const long long list0 = (long long)blockIdx.x * nl;
+  const long long list0 = p.list_base + (long long)blockIdx.x * nl;
   float* const Pa = smem + p.p1_off;
   float* const Pb = smem + p.p2_off;
   const int PSa = p.PS, PSb = p.PS2;
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain32_kernel(TcArgs p) {
   TC_WSTAMP(9);
   lds_barrier();
   {
-    float* out = p.outpart + (long long)blockIdx.x * (3 * Ko + 4);
+    float* out = p.outpart + (long long)(p.part_base + blockIdx.x) * (3 * Ko + 4);
     const int stride = 3 * Ko + 1;
     for (int i = tid; i < stride; i += kTcThreads) {
       float s = 0.f;

@@ -53,6 +53,7 @@ struct TcArgs {
   const float* table; int ldx; const int* docids; int n_rows; const float* row_stats;
   int has_ln; float eps; int activation; int H;
   int B, L, nl;                                   // nl lists of L ranks per workgroup, nl * L <= 16
+  int list_base, part_base;                       // workgroup i owns lists list_base + i * nl ..., partial row part_base + i
   const float* W[ULTR_MAX_LAYERS]; const float* WT[ULTR_MAX_LAYERS];
   // bf16 instantiations stream these instead: W_j resp. W_j^T packed [rows / 4][ld][4] bf16 (pack_weights_kernel)
   const float* Wp[ULTR_MAX_LAYERS]; const float* WTp[ULTR_MAX_LAYERS];
@@ -62,7 +63,7 @@ struct TcArgs {
   float* dz[ULTR_MAX_LAYERS];                     // [M][ldn_j]        gradient wrt layer j's pre-activation
   float* scores;                                  // [L][B] position-major
   float* list_weights;                            // [B] or NULL
-  float* outpart;                                 // [gridDim.x][3 K_H + 4] output-layer gradient partials
+  float* outpart;                                 // [workgroups of the step][3 K_H + 4] output-layer gradient partials
   int PS;                                         // row stride of the two LDS panels (== 4 mod 32)
   int PS2;                                        // 32-row kernel: row stride of the second panel (hidden widths only)
   int panel_floats;                               // floats per panel
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   const int L = p.L, B = p.B, nl = p.nl, H = p.H, PS = p.PS;
   const bool has_ln = FAST ? true : p.has_ln != 0;
   const int act = p.activation;
-  const long long list0 = (long long)blockIdx.x * nl;
+  const long long list0 = p.list_base + (long long)blockIdx.x * nl;
   float* P1 = smem + p.p1_off;
   float* P2 = smem + p.p2_off;
   float* s_stat = smem + p.misc_off;                       // [layer][16][2]
@@ -891,7 +892,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   TC_WSTAMP(9);
   lds_barrier();
   {
-    float* out = p.outpart + (long long)blockIdx.x * (3 * Ko + 4);
+    float* out = p.outpart + (long long)(p.part_base + blockIdx.x) * (3 * Ko + 4);
     const int stride = 3 * Ko + 1;
     for (int i = tid; i < stride; i += kTcThreads) {
       float s = 0.f;
@@ -1242,9 +1243,19 @@ __global__ void __launch_bounds__(kThreads) finalize_fused_kernel(FinalizeFusedA
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// LDS geometry of the 16-row kernel
+struct Chain16Geo {
+  int PS, panel_floats, act_off[ULTR_MAX_LAYERS], act_ps[ULTR_MAX_LAYERS], p1_off, p2_off, misc_off;
+  size_t smem_bytes;
+  bool ok;
+};
 struct FusedPlan {
   int H, nl, nwg;
   int rows;  // 16: train_chain_kernel; 32: train_chain32_kernel (batches of more than one workgroup per CU)
+  // rows == 32 only: the batch's last lists as a second launch of 16-row workgroups (tail_nwg of them, tail_nl lists each,
+  // from list tail_base on) when that ends sooner than a last, mostly empty round of 32-row workgroups; 0: none
+  int tail_nwg, tail_nl, tail_base;
+  Chain16Geo tail;
   int PS2;
   bool fast;  // the reference's default scorer with aligned widths: the compile-time specialised kernels
   int K[ULTR_MAX_LAYERS], N[ULTR_MAX_LAYERS], ldn[ULTR_MAX_LAYERS];
@@ -1264,6 +1275,24 @@ struct FusedPlan {
 static int fused_rows_override() {
   static const int v = [] { const char* e = getenv("ULTR_FUSED_ROWS"); return e ? atoi(e) : 0; }();
   return v;
+}
+static Chain16Geo chain16_geo(int H, const int* N, int KH, int maxw) {
+  Chain16Geo G{};
+  G.PS = ((maxw + 31) & ~31) + 4;
+  G.panel_floats = kTcRows * G.PS > kTcExch ? kTcRows * G.PS : kTcExch;
+  if (8 * (3 * KH + 1) > G.panel_floats) return G;
+  int off = 0;
+  for (int j = 0; j < H; ++j) {
+    G.act_ps[j] = ((N[j] + 31) & ~31) + 4;
+    G.act_off[j] = off;
+    off += kTcRows * G.act_ps[j];
+  }
+  G.p1_off = off; off += G.panel_floats;
+  G.p2_off = off; off += G.panel_floats;
+  G.misc_off = off; off += kTcMiscFloats;
+  G.smem_bytes = sizeof(float) * (size_t)off;
+  G.ok = G.smem_bytes <= 160 * 1024;
+  return G;
 }
 static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   FusedPlan P{};
@@ -1286,6 +1315,8 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
   P.fast = d->activation == ULTR_ACT_ELU && d->norm == ULTR_NORM_LAYER && (P.K[0] & 3) == 0;
   for (int j = 1; j <= P.H; ++j) P.fast = P.fast && (P.K[j] & 15) == 0;
   const int nl16 = 16 / L > 4 ? 4 : 16 / L;  // one 16-lane group per list in the loss lanes of a wave
+  const Chain16Geo g16 = chain16_geo(P.H, P.N, P.K[P.H], maxw);
+  constexpr int kCUs = 256;
   // ---- 32 rows per workgroup?
   P.rows = 16;
   {
@@ -1296,7 +1327,7 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
     const size_t bytes = sizeof(float) * ((size_t)pa + pb + kC32MiscFloats);
     const bool can32 = P.fast && !P.bf16 && maxw <= 768 && nl32 > nl16 && bytes <= 160 * 1024 && 8 * (3 * P.K[P.H] + 1) <= pb;
     const int ov = fused_rows_override();
-    if (can32 && (ov == 32 || (ov != 16 && cdiv(B, nl16) > 256))) {
+    if (can32 && (ov == 32 || (ov != 16 && cdiv(B, nl16) > kCUs))) {
       P.rows = 32;
       P.nl = nl32;
       P.nwg = (int)cdiv(B, P.nl);
@@ -1304,25 +1335,28 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
       P.panel_floats = pa;
       P.p1_off = 0; P.p2_off = pa; P.misc_off = pa + pb;
       P.smem_bytes = bytes;
+      // One workgroup per CU at a time, so the launch runs in rounds of 256 workgroups and a last round of a few
+      // workgroups costs as much as a full one.  A 16-row workgroup takes about 0.6 of the time of a 32-row one: when the
+      // lists beyond the last full round fit ONE round of 16-row workgroups, they run as a second launch of those
+      // (B = 4096, lists of 10: 5 rounds of 3 lists + 256 single lists instead of 6 rounds).
+      const long long full = (long long)(P.nwg / kCUs) * kCUs, rest = B - full * nl32;
+      if (ov != 32 && g16.ok && full > 0 && rest > 0 && rest <= (long long)kCUs * nl16) {
+        P.nwg = (int)full;
+        P.tail = g16;
+        P.tail_nl = nl16;
+        P.tail_base = (int)(full * nl32);
+        P.tail_nwg = (int)cdiv(rest, nl16);
+      }
     }
   }
   if (P.rows == 16) {
-  P.nl = nl16;
-  P.nwg = (int)cdiv(B, P.nl);
-  P.PS = ((maxw + 31) & ~31) + 4;
-  P.panel_floats = kTcRows * P.PS > kTcExch ? kTcRows * P.PS : kTcExch;
-  if (8 * (3 * P.K[P.H] + 1) > P.panel_floats) return P;
-  int off = 0;
-  for (int j = 0; j < P.H; ++j) {
-    P.act_ps[j] = ((P.N[j] + 31) & ~31) + 4;
-    P.act_off[j] = off;
-    off += kTcRows * P.act_ps[j];
-  }
-  P.p1_off = off; off += P.panel_floats;
-  P.p2_off = off; off += P.panel_floats;
-  P.misc_off = off; off += kTcMiscFloats;
-  P.smem_bytes = sizeof(float) * (size_t)off;
-  if (P.smem_bytes > 160 * 1024) return P;
+    if (!g16.ok) return P;
+    P.nl = nl16;
+    P.nwg = (int)cdiv(B, P.nl);
+    P.PS = g16.PS; P.panel_floats = g16.panel_floats;
+    for (int j = 0; j < P.H; ++j) { P.act_ps[j] = g16.act_ps[j]; P.act_off[j] = g16.act_off[j]; }
+    P.p1_off = g16.p1_off; P.p2_off = g16.p2_off; P.misc_off = g16.misc_off;
+    P.smem_bytes = g16.smem_bytes;
   }
   long long o = 0;
   auto take = [&](long long n) {
@@ -1348,7 +1382,7 @@ static FusedPlan make_fused_plan(const UltrDnnDesc* d, int B, int L) {
     P.gslab[j] = take((long long)P.nsplit * P.K[j] * P.ldn[j]);
     P.sslab[j] = take((long long)P.nsplit * P.ldn[j]);
   }
-  P.outpart = take((long long)P.nwg * (3 * P.K[P.H] + 4));
+  P.outpart = take((long long)(P.nwg + P.tail_nwg) * (3 * P.K[P.H] + 4));
   P.total = o;
   P.ok = true;
   return P;
@@ -1409,6 +1443,12 @@ extern "C" int ultr_dnn_fused_rows(const UltrDnnDesc* desc, int B, int L) {
   return P.ok ? P.rows : 0;
 }
 
+extern "C" int ultr_dnn_fused_tail_lists(const UltrDnnDesc* desc, int B, int L) {
+  if (ultr_check_desc(desc, "ultr_dnn_fused_tail_lists") != ULTR_OK) return -1;
+  const FusedPlan P = make_fused_plan(desc, B, L);
+  return P.ok && P.tail_nwg > 0 ? B - P.tail_base : 0;
+}
+
 extern "C" long long ultr_dnn_fused_workspace_bytes(const UltrDnnDesc* desc, int B, int L) {
   if (ultr_check_desc(desc, "ultr_dnn_fused_workspace_bytes") != ULTR_OK) return -1;
   const FusedPlan P = make_fused_plan(desc, B, L);
@@ -1423,8 +1463,12 @@ static int launch_chain3(const TcArgs& a, int nwg, size_t smem, hipStream_t st) 
   long long pw = 0;
   for (int j = 0; j < a.H; ++j) pw += (long long)a.K[j] * a.N[j] + (j >= 1 ? (long long)a.K[j] * a.N[j] : 0);
   {
-    ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern(BF ? "train_chain_kernel_bf16/P%lld" : "train_chain_kernel/P%lld", pw)
-                                             : "train_chain_kernel", st);
+    // (a launch that covers part of the batch carries its row count: the tail launch beside train_chain32_kernel)
+    const long long part_rows = (long long)a.L * ((long long)nwg * a.nl < a.B - a.list_base ? (long long)nwg * a.nl : a.B - a.list_base);
+    const bool part = part_rows != (long long)a.B * a.L;
+    ultr::ProfScope prof_(!ultr::g_profile_on ? "train_chain_kernel"
+                          : part ? ultr::profile_intern("train_chain_kernel/P%lldM%lld", pw, part_rows)
+                                 : ultr::profile_intern(BF ? "train_chain_kernel_bf16/P%lld" : "train_chain_kernel/P%lld", pw), st);
     hipLaunchKernelGGL((train_chain_kernel<RIDE, FAST, NQ, BF>), dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
   }
   return check_launch("train_chain_kernel");
@@ -1437,7 +1481,11 @@ static int launch_chain32(const TcArgs& a, int nwg, size_t smem, hipStream_t st)
   long long pw = 0;
   for (int j = 0; j < a.H; ++j) pw += (long long)a.K[j] * a.N[j] + (j >= 1 ? (long long)a.K[j] * a.N[j] : 0);
   {
-    ultr::ProfScope prof_(ultr::g_profile_on ? ultr::profile_intern("train_chain32_kernel/P%lld", pw) : "train_chain32_kernel", st);
+    const long long part_rows = (long long)a.L * ((long long)nwg * a.nl < a.B ? (long long)nwg * a.nl : a.B);
+    const bool part = part_rows != (long long)a.B * a.L;
+    ultr::ProfScope prof_(!ultr::g_profile_on ? "train_chain32_kernel"
+                          : part ? ultr::profile_intern("train_chain32_kernel/P%lldM%lld", pw, part_rows)
+                                 : ultr::profile_intern("train_chain32_kernel/P%lld", pw), st);
     hipLaunchKernelGGL((train_chain32_kernel<RIDE, NQ>), dim3((unsigned)nwg), dim3(kTcThreads), smem, st, a);
   }
   return check_launch("train_chain32_kernel");
@@ -1572,6 +1620,18 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
   else if (pl.kind == ULTR_RIDE_REM) rc = launch_chain<ULTR_RIDE_REM>(a, P.nwg, P.smem_bytes, fast, st);
   else rc = launch_chain<ULTR_RIDE_PD>(a, P.nwg, P.smem_bytes, fast, st);
   if (rc) return rc;
+  if (P.tail_nwg > 0) {  // the lists beyond the last full round of 32-row workgroups
+    TcArgs t = a;
+    t.nl = P.tail_nl; t.list_base = P.tail_base; t.part_base = P.nwg;
+    t.PS = P.tail.PS; t.PS2 = 0; t.panel_floats = P.tail.panel_floats;
+    t.p1_off = P.tail.p1_off; t.p2_off = P.tail.p2_off; t.misc_off = P.tail.misc_off;
+    for (int j = 0; j < H; ++j) { t.act_off[j] = P.tail.act_off[j]; t.act_ps[j] = P.tail.act_ps[j]; }
+    if (pl.kind == ULTR_RIDE_DLA) rc = launch_chain<ULTR_RIDE_DLA>(t, P.tail_nwg, P.tail.smem_bytes, fast, st);
+    else if (pl.kind == ULTR_RIDE_IPW) rc = launch_chain<ULTR_RIDE_IPW>(t, P.tail_nwg, P.tail.smem_bytes, fast, st);
+    else if (pl.kind == ULTR_RIDE_REM) rc = launch_chain<ULTR_RIDE_REM>(t, P.tail_nwg, P.tail.smem_bytes, fast, st);
+    else rc = launch_chain<ULTR_RIDE_PD>(t, P.tail_nwg, P.tail.smem_bytes, fast, st);
+    if (rc) return rc;
+  }
 
   // ---- every weight-gradient GEMM
   {
@@ -1604,7 +1664,7 @@ extern "C" int ultr_dnn_train_fused(const UltrDnnDesc* desc, const float* params
     f.off_gamma[j] = desc->off_gamma[j]; f.off_beta[j] = desc->off_beta[j];
   }
   f.params = params; f.grads = grads; f.has_ln = has_ln;
-  f.outpart = ws + P.outpart; f.out_blocks = P.nwg; f.Kout = P.K[H];
+  f.outpart = ws + P.outpart; f.out_blocks = P.nwg + P.tail_nwg; f.Kout = P.K[H];
   f.sumsq = sumsq;
   const unsigned fblocks = (unsigned)(start + (3 * P.K[H] + 1 + kFinOutCols - 1) / kFinOutCols);
   // too big to ride along, or lists of at most 8 (the rider is compiled for 16-lane groups): a launch of its own

@@ -215,6 +215,10 @@ class DNN(BaseRankingModel):
         """Rows per workgroup of the fused step for (B, L): 16, 32 (large batches, chain32.hpp) or 0 (not supported)."""
         return int(_lib.lib().ultr_dnn_fused_rows(self.desc, int(B), int(L)))
 
+    def fused_tail_lists(self, B, L):
+        """Lists of (B, L) that the fused step hands to a second launch of 16-row workgroups (0: one launch)."""
+        return int(_lib.lib().ultr_dnn_fused_tail_lists(self.desc, int(B), int(L)))
+
     def _fused_workspace(self, B, L):
         key = ('fused', B, L)
         if key not in self._ws:
