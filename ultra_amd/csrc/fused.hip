@@ -1110,10 +1110,19 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int b
       float* slot = ring + (c % kWgStages) * kWgSlot + 8 * w * 64;
       const float* ap = a_src + (size_t)c * a_step;
       const float* bp = b_src + (size_t)c * b_step;
-      __builtin_amdgcn_global_load_lds(ap, ULTR_LDS_PTR(slot), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(ap + a_row4, ULTR_LDS_PTR(slot + 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(bp, ULTR_LDS_PTR(slot + kWgTile), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(bp + b_row4, ULTR_LDS_PTR(slot + kWgTile + 256), 16, 0, 0);
+      // Through asm, not the builtin: the compiler books an LDS-DMA load on the LDS counter as well (as if it were a flat
+      // access that may complete out of order), and from then on every wait for an LDS READ in the loop is lgkmcnt(0)
+      // -- the multiply loop below then waits for the operands it has just requested instead of the ones it needs.
+      // The hardware counts these loads on vmcnt only, which the loop waits for by hand anyway.
+      const unsigned l0 = (unsigned)(size_t)ULTR_LDS_PTR(slot);
+      asm volatile(
+          "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+          "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+          "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off"
+          :
+          : "v"(ap), "v"(ap + a_row4), "v"(bp), "v"(bp + b_row4), "s"(l0), "s"(l0 + 0x400u), "s"(l0 + 0x2000u), "s"(l0 + 0x2400u)
+          : "memory");  // (m0 is written; it cannot be named as a clobber, and nothing else in this kernel uses it)
     }
   };
   WG_STAMP(0);
@@ -1154,13 +1163,25 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradArgs& p, int bx, int b
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, ua), __builtin_bit_cast(wg_bf16x8, ub), acc, 0, 0, 0);
       }
     } else {
+      // pinned order: the operands of MFMA pair q + 1 are requested before pair q is issued, so that only the first
+      // pair's LDS latency stands in front of the chunk's multiplies
+      auto rd = [&](int q) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        a[t] = slot[a_off + 128 * t];
-        b[t] = slot[b_off + 128 * t];
+        for (int t = 2 * q; t < 2 * q + 2; ++t) {
+          a[t] = slot[a_off + 128 * t];
+          b[t] = slot[b_off + 128 * t];
+        }
+      };
+      rd(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < 7) rd(q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q], b[2 * q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * q + 1], b[2 * q + 1], acc, 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (do_colsum) {
       float s4[4];
