@@ -165,7 +165,10 @@ __global__ void __launch_bounds__(kTcThreads) train_chain32_kernel(TcArgs p) {
   }
   int docid[4];
 #pragma unroll
-  for (int r4 = 0; r4 < 4; ++r4) docid[r4] = rvalid[r4] ? p.docids[re[r4]] : p.n_rows;
+  for (int r4 = 0; r4 < 4; ++r4) {  // (load, then select: see train_chain_kernel)
+    const int dv = p.docids[re[r4]];
+    docid[r4] = rvalid[r4] ? dv : p.n_rows;
+  }
   // ---- the lane's element of the loss: list list0 + lane / 16, rank lane % 16 (loads now, arithmetic later)
   const int li_l = lane >> 4, r_l = lane & 15;
   const long long b_l = list0 + li_l;

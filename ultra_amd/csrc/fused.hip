@@ -400,7 +400,13 @@ __global__ void __launch_bounds__(kTcThreads) train_chain_kernel(TcArgs p) {
   // trip); only then the first weight chunks and the L2 warm-up touches, which nothing waits for before the GEMM.
   int docid[2];
 #pragma unroll
-  for (int r2 = 0; r2 < 2; ++r2) docid[r2] = rvalid[r2] ? p.docids[re[r2]] : p.n_rows;
+  for (int r2 = 0; r2 < 2; ++r2) {
+    // loaded on every path (re is 0 for a row that is not there) and selected afterwards: `valid ? docids[e] : n_rows`
+    // becomes a load from a SELECTED address -- global memory or the kernel-argument segment, hence a flat load, and
+    // while a flat load is in flight every wait of the wave has to be a wait for everything
+    const int dv = p.docids[re[r2]];
+    docid[r2] = rvalid[r2] ? dv : p.n_rows;
+  }
   // ---- the lane's element of the loss: list list0 + lane / 16, rank lane % 16 (loads now, arithmetic later)
   const int li_l = lane >> 4, r_l = lane & 15;
   const long long b_l = list0 + li_l;
