@@ -401,6 +401,47 @@ def test_library_exports_every_declared_symbol():
     assert b'null pointer' in lib.ultr_last_error()
 
 
+def _scorer_desc(F, hidden, dtype=0):
+    """The descriptor DNN.py builds for the reference's default scorer (elu, layer normalisation)."""
+    from ultra_amd import _lib
+    d = _lib.UltrDnnDesc()
+    sizes = list(hidden) + [1]
+    d.n_layers, d.in_features, d.activation, d.norm, d.ln_eps, d.compute_dtype = len(sizes), F, _lib.ACT['elu'], _lib.NORM_LAYER, 1e-3, dtype
+    off, k = 0, F
+    for j, n in enumerate(sizes):
+        ldw = 1 if j == len(sizes) - 1 else (n + 3) // 4 * 4
+        d.sizes[j] = n
+        for name, length in (('W', k * ldw), ('b', n), ('gamma', k), ('beta', k)):
+            getattr(d, 'off_' + name)[j] = off
+            off += (length + 63) // 64 * 64
+        k = n
+    d.n_params = off
+    return d
+
+
+def test_fused_plan_splits_large_batches_into_whole_rounds_and_a_tail():
+    """Host-side plan only (no launch): 32-row workgroups in whole rounds of 256, the rest on 16-row workgroups when
+    that rest fits one round of them (fused.hip: make_fused_plan)."""
+    from ultra_amd import _lib
+    lib = _lib.lib()
+    d = _scorer_desc(136, [512, 256, 128])
+    rows = lambda B, L: lib.ultr_dnn_fused_rows(ctypes.byref(d), B, L)
+    tail = lambda B, L: lib.ultr_dnn_fused_tail_lists(ctypes.byref(d), B, L)
+    assert (rows(256, 10), tail(256, 10)) == (16, 0)
+    assert (rows(257, 10), tail(257, 10)) == (32, 0)       # 86 workgroups of three lists: less than a round
+    assert (rows(768, 10), tail(768, 10)) == (32, 0)       # exactly one round
+    assert (rows(769, 10), tail(769, 10)) == (32, 1)
+    assert (rows(1024, 10), tail(1024, 10)) == (32, 256)
+    assert (rows(1025, 10), tail(1025, 10)) == (32, 0)     # 257 lists left: more than a round of 16-row workgroups
+    assert (rows(4096, 10), tail(4096, 10)) == (32, 256)   # BASELINE config 5: 1280 x 3 lists + 256 x 1
+    assert (rows(1300, 8), tail(1300, 8)) == (32, 276)     # four lists of 8 per 32 rows, two per 16
+    assert (rows(600, 16), tail(600, 16)) == (32, 88)
+    assert lib.ultr_dnn_fused_workspace_bytes(ctypes.byref(d), 4096, 10) > 0
+    b = _scorer_desc(136, [512, 256, 128], dtype=_lib.DTYPE_BF16)   # the bf16 step keeps the 16-row kernel
+    assert (lib.ultr_dnn_fused_rows(ctypes.byref(b), 4096, 10), lib.ultr_dnn_fused_tail_lists(ctypes.byref(b), 4096, 10)) == (16, 0)
+    assert lib.ultr_dnn_fused_rows(ctypes.byref(d), 64, 17) == 0       # lists longer than 16: the per-launch plan
+
+
 def test_product_does_not_import_the_oracle():
     pat = re.compile(r'^\s*(from|import)\s+[\w.]*oracle[\w.]*(\s|$)', re.M)
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'ultra_amd')):
