@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(kTcThreads) train_chain32_kernel(TcArgs p) {
     }
     if (RIDE == ULTR_RIDE_REM) {
       if (live) ds = rem_elem_v(p.rem, rem_bias, rem_p, rem_step, b_l, r_l, e_l, o, c_l).d;
-      lw = group_sum<16>(live ? cl / rem_p : 0.f);
+      lw = group_sum<16>(live ? cl * (1.f / rem_p) : 0.f);  // clicks x (1 / propensity), as every REM kernel forms it
     }
     if (!live) ds = 0.f;
     if (w == 0 && live && r_l == 0 && p.list_weights && RIDE != ULTR_RIDE_PD) p.list_weights[b_l] = lw / (float)L;

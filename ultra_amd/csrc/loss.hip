@@ -304,12 +304,6 @@ __global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
       const float x = scores[e] + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
       c = clicks[e];
       const float p = propensity[l];
-      const float g = sigmoidf_(x);
-      const float den = 1.f - p * g;
-      const float p_e1_r0_c0 = p * (1.f - g) / den;  // :140-141
-      const float p_e0_r1_c0 = (1.f - p) * g / den;  // :142-143
-      const float p_r1 = c + (1.f - c) * p_e0_r1_c0;  // :147-148
-      mstep = c + (1.f - c) * p_e1_r0_c0;             // :153
       float u;
       if (uniforms) {
         u = uniforms[e];
@@ -318,14 +312,14 @@ __global__ void __launch_bounds__(kLossThreads) rem_loss_kernel(
                                              (uint32_t)seed, (uint32_t)(seed >> 32));
         u = u24(philox_word(rnd, l));
       }
-      y = ceilf(p_r1 - u);  // get_bernoulli_sample (:39)
-      y = y > 0.f ? y : 0.f;  // ceil(-0.x) = -0 -> 0
-      loss += sig_ce(y, x);   // :159-165
-      const float d = g - y;
-      d_scores[e] = d;
-      dsum += d;
+      const RemElem v = rem_elem_u(bias, p, scores[e], c, u);  // the one definition of the element (loss_body.hpp)
+      mstep = c + (1.f - c) * v.p_e1_r0_c0;  // :153
+      y = v.y;
+      loss += sig_ce_fast(y, x);  // :159-165
+      d_scores[e] = v.d;
+      dsum += v.d;
       if (ranker_labels) ranker_labels[e] = y;
-      lw += fminf(fmaxf(c, 0.f), 1.f) / p;  // propensity_weights = 1/propensity (:176)
+      lw += fminf(fmaxf(c, 0.f), 1.f) * (1.f / p);  // propensity_weights = 1/propensity (:176)
     }
     bs.add(2 + l, mstep);
     bs.add(2 + L + l, y);

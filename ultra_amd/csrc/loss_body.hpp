@@ -128,6 +128,8 @@ __device__ __forceinline__ DlaTower dla_tower(const float* __restrict__ prop_par
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_log(float x) { return __logf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// sig_ce with the hardware exp / log: for loss STATISTICS (absolute error ~1e-7 per element), never for a gradient
+__device__ __forceinline__ float sig_ce_fast(float z, float x) { return fmaxf(x, 0.f) - x * z + fast_log(1.f + fast_exp(-fabsf(x))); }
 struct DlaLane { float m, ex, se, wl, S, lse, ds, sm; };
 __device__ __forceinline__ DlaLane dla_lane(float o, float c, float pw, bool live, int loss_func) {
 #pragma clang fp contract(off)
@@ -498,15 +500,20 @@ struct RemArgs {
 // One (list b, rank r) element: E-step posteriors, the Bernoulli ranker label and d loss / d score = sigmoid - label.
 // Elementwise, so the backward pass's first launch can evaluate it for its own rows (ultr_loss_rem_deferred).
 struct RemElem { float x, g, y, d, p_e1_r0_c0; };
-// rem_elem_u: the arithmetic, given the element's uniform draw.
+// rem_elem_u: the arithmetic, given the element's uniform draw.  ONE definition for every kernel that evaluates it (the
+// 16-lane and lane-per-list bodies, the long-list kernel, the riders of the fused step), so that the same inputs give
+// the same label everywhere.  The sigmoid and the shared 1 / (1 - p g) take the hardware exp and reciprocal (1 ulp each,
+// like dla_lane): with libm's expf and three IEEE divides an element cost ~290 instructions and the kernel ran at a
+// fifth of the memory rate; a label can differ from the float64 oracle's only where p_r1 - u is within rounding of 0,
+// which was so before (test_rem_loss_kernel bounds the rate).
 __device__ __forceinline__ RemElem rem_elem_u(float bias, float p, float score, float c, float u) {
 #pragma clang fp contract(off)
   RemElem v;
   v.x = score + bias;  // train_output + sigmoid_prob_b (regression_EM.py:119)
-  v.g = sigmoidf_(v.x);
-  const float den = 1.f - p * v.g;
-  v.p_e1_r0_c0 = p * (1.f - v.g) / den;              // :140-141
-  const float p_e0_r1_c0 = (1.f - p) * v.g / den;    // :142-143
+  v.g = fast_rcp(1.f + fast_exp(-v.x));
+  const float rden = fast_rcp(1.f - p * v.g);
+  v.p_e1_r0_c0 = p * (1.f - v.g) * rden;              // :140-141
+  const float p_e0_r1_c0 = (1.f - p) * v.g * rden;    // :142-143
   const float p_r1 = c + (1.f - c) * p_e0_r1_c0;     // :147-148
   v.y = ceilf(p_r1 - u);      // get_bernoulli_sample (:39)
   v.y = v.y > 0.f ? v.y : 0.f;  // ceil(-0.x) = -0 -> 0
@@ -539,6 +546,7 @@ __device__ __forceinline__ void rem_loss_small_body(const RemArgs& a, unsigned i
   const bool in_list = r < L;
   const float bias = a.bias_ptr ? a.bias_ptr[0] : 0.f;
   const float p = in_list ? a.propensity[r] : 1.f;
+  const float rp = 1.f / p;
   const unsigned int step = a.step + (a.step_ctr ? a.step_ctr[0] : 0u);  // device-resident step counter (read-only here)
   float loss = 0.f, cnt = 0.f, dsum = 0.f, ms = 0.f, ys = 0.f, cs = 0.f;
   for (long long b0 = (long long)bid * 16; b0 < B; b0 += (long long)nb * 16) {
@@ -549,14 +557,14 @@ __device__ __forceinline__ void rem_loss_small_body(const RemArgs& a, unsigned i
     if (live) {
       const RemElem v = rem_elem(a, bias, p, step, b, r, e);
       const float c = a.clicks[e];
-      loss += sig_ce(v.y, v.x);       // :159-165
+      loss += sig_ce_fast(v.y, v.x);  // :159-165
       a.d_scores[e] = v.d;
       dsum += v.d;
       if (a.ranker_labels) a.ranker_labels[e] = v.y;
       ms += c + (1.f - c) * v.p_e1_r0_c0;  // :153
       ys += v.y;
       cs += c;
-      lwt = fminf(fmaxf(c, 0.f), 1.f) / p;  // propensity_weights = 1/propensity (:176)
+      lwt = fminf(fmaxf(c, 0.f), 1.f) * rp;  // propensity_weights = 1/propensity (:176)
       cnt += r == 0 ? 1.f : 0.f;
     }
     const float lw = group_sum<16>(lwt);
@@ -596,10 +604,11 @@ __device__ __forceinline__ void rem_loss_lists_body(const RemArgs& a, unsigned i
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float bias = a.bias_ptr ? a.bias_ptr[0] : 0.f;
   const unsigned int step = a.step + (a.step_ctr ? a.step_ctr[0] : 0u);
-  float p[LT], ms[LT], ys[LT], cs[LT];
+  float p[LT], rp[LT], ms[LT], ys[LT], cs[LT];
 #pragma unroll
   for (int l = 0; l < LT; ++l) {
     p[l] = a.propensity[l];
+    rp[l] = 1.f / p[l];
     ms[l] = ys[l] = cs[l] = 0.f;
   }
   float loss = 0.f, cnt = 0.f, dsum = 0.f;
@@ -622,14 +631,14 @@ __device__ __forceinline__ void rem_loss_lists_body(const RemArgs& a, unsigned i
         rnd = philox4x32_10(a.slot_base + b, 0x52454Du, (uint32_t)(l >> 2), step, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
       const uint32_t word = (l & 3) == 0 ? rnd.w0 : (l & 3) == 1 ? rnd.w1 : (l & 3) == 2 ? rnd.w2 : rnd.w3;
       const RemElem v = rem_elem_u(bias, p[l], o[l], c[l], u24(word));
-      loss += sig_ce(v.y, v.x);       // :159-165
+      loss += sig_ce_fast(v.y, v.x);  // :159-165
       *at_w(a.d_scores + (long long)l * B, off) = v.d;
       dsum += v.d;
       if (a.ranker_labels) *at_w(a.ranker_labels + (long long)l * B, off) = v.y;
       ms[l] += c[l] + (1.f - c[l]) * v.p_e1_r0_c0;  // :153
       ys[l] += v.y;
       cs[l] += c[l];
-      lwt += fminf(fmaxf(c[l], 0.f), 1.f) / p[l];  // propensity_weights = 1/propensity (:176)
+      lwt += fminf(fmaxf(c[l], 0.f), 1.f) * rp[l];  // propensity_weights = 1/propensity (:176)
     }
     cnt += 1.f;
     if (a.list_weights) a.list_weights[b] = lwt / (float)LT;
