@@ -797,8 +797,12 @@ extern "C" int ultr_rem_update_propensity(float* propensity, int L, const float*
 
 // Many short lists (B >= kDlaListsMinB, L <= kPdListsMaxL): one lane per list, body in loss_body.hpp.
 constexpr int kPdListsMaxL = 12;  // LT * LT pair sums per lane in registers
-template <int LT>
-__global__ void __launch_bounds__(kLossThreads) pd_loss_lists_kernel(PdArgs a) {
+// OCC workgroups per CU asked of the register allocator: left alone it takes 286 registers for lists of 10 (one wave
+// per SIMD, every transcendental chain exposed); held to 256 (two waves per SIMD, a few spilled row pointers) the kernel
+// runs 72.8 -> 64.6 us at 2^20 lists but 16.7 -> 18.6 us at 65536, where a CU has one workgroup either way -- so OCC = 2
+// from 131072 lists on, for lists of at most 10 (lists of 12 would spill 160 values).
+template <int LT, int OCC>
+__global__ void __launch_bounds__(kLossThreads, OCC) pd_loss_lists_kernel(PdArgs a) {
   __shared__ float s_acc[kMaxStat];
   __shared__ float s_part[4 * kMaxStat];
   __shared__ float s_t[32 + LT * LT];
@@ -806,8 +810,10 @@ __global__ void __launch_bounds__(kLossThreads) pd_loss_lists_kernel(PdArgs a) {
 }
 template <int LT>
 static void launch_pd_lists(const PdArgs& a, unsigned nb, hipStream_t st) {
-  if (a.L == LT) hipLaunchKernelGGL(pd_loss_lists_kernel<LT>, dim3(nb), dim3(kLossThreads), 0, st, a);
-  else if constexpr (LT > 2) launch_pd_lists<LT - 1>(a, nb, st);
+  if (a.L == LT) {
+    if (LT <= 10 && a.B >= 131072) hipLaunchKernelGGL((pd_loss_lists_kernel<LT, (LT <= 10 ? 2 : 1)>), dim3(nb), dim3(kLossThreads), 0, st, a);
+    else hipLaunchKernelGGL((pd_loss_lists_kernel<LT, 1>), dim3(nb), dim3(kLossThreads), 0, st, a);
+  } else if constexpr (LT > 2) launch_pd_lists<LT - 1>(a, nb, st);
 }
 
 extern "C" int ultr_loss_pd_fwdbwd(const float* scores, const float* clicks, int B, int L, const float* t_plus,

@@ -767,7 +767,6 @@ __device__ __forceinline__ void pd_loss_small_body(const PdArgs& a, unsigned int
 template <int LT>
 __device__ __forceinline__ void pd_loss_lists_body(const PdArgs& a, unsigned int bid, unsigned int nb, float* s_acc,
                                                    float* s_part, float* s_t /* [32 + LT * LT] */) {
-#pragma clang fp contract(off)
   const int B = a.B;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float* s_tp = s_t;
@@ -821,10 +820,11 @@ __device__ __forceinline__ void pd_loss_lists_body(const PdArgs& a, unsigned int
         // a wave -- and 45 branches cut the loop body into blocks of one dependent chain each, 13 cycles per instruction)
         const float wkj = s_w[k * LT + j], wjk = s_w[j * LT + k];
         const float t = m * (kwins ? wkj : wjk) * sg;
+        const float ts = kwins ? t : -t;  // what rank j's gradient gains and rank k's loses
         pl[k][j] += kwins ? val : 0.f;
         pl[j][k] += kwins ? 0.f : val;
-        acc[k] += kwins ? -t : t;
-        acc[j] += kwins ? t : -t;
+        acc[k] -= ts;
+        acc[j] += ts;
       }
 #pragma unroll
     for (int l = 0; l < LT; ++l) *at_w(a.d_scores + (long long)l * B, off) = acc[l];
